@@ -1,0 +1,155 @@
+/*
+ * rt_capi.h -- the drop-in boundary: a C ABI for "render every pixel of a
+ * rectangle" on an AMD MI355X (gfx950).
+ *
+ * The reference (ccelio/TileCodeRayTracer) has no plugin/FFI seam: main() takes
+ * no arguments and the renderer is the direct call
+ *     pixels[x][z] = calculatePixel(createEyeRay(x/W, z/H), 0)
+ * inside raytrace_main()'s pixel loop (src/RayTracer.cpp:904-923).  This
+ * header cuts the seam exactly there.  Above it sits the reference's C++
+ * object model (Scene / SceneObject / Camera, mirrored in
+ * tilecoderaytracer_amd/csrc/host/); below it are plain-old-data tables and
+ * hand-written HIP kernels.  No C++ or torch types cross this boundary.
+ *
+ * Conventions kept from the reference: every call returns int, 0 = ok,
+ * non-zero = error (Scene::initialize / init_log / raytrace_main,
+ * src/Scene.cpp:386, src/RayTracer.cpp:862-873, 2027-2031); nothing throws or
+ * aborts across the ABI; rt_last_error() gives the text for the calling thread.
+ *
+ * There is NO CPU fallback behind this ABI.  If no HIP device is usable every
+ * call that needs one fails with RT_ERR_NO_DEVICE.
+ */
+#ifndef RT_CAPI_H_
+#define RT_CAPI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_CAPI_VERSION 1
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,      /* bad argument / malformed description        */
+    RT_ERR_NO_DEVICE = 2,    /* no usable HIP device                        */
+    RT_ERR_HIP = 3,          /* a HIP runtime call failed                   */
+    RT_ERR_CAPACITY = 4,     /* scene + bounce stack do not fit in LDS      */
+    RT_ERR_RCCL = 5          /* an RCCL call failed (rt_render_multi)       */
+};
+
+/* primitive kinds: SceneSphere / SceneInfinitePlane / SceneFinitePlane
+ * (src/SceneSphere.h:10, src/SceneInfinitePlane.h:16, src/SceneFinitePlane.h:16) */
+enum { RT_KIND_SPHERE = 0, RT_KIND_INFINITE_PLANE = 1, RT_KIND_FINITE_PLANE = 2 };
+
+/* One scene object, flattened: the members of SceneObject
+ * (src/SceneObject.h:189-199), its ObjMaterial (src/ObjMaterial.h:69-79) and
+ * the derived geometry each primitive's constructor computes
+ * (src/SceneSphere.cpp:44-48, src/SceneInfinitePlane.cpp:11-26,
+ * src/SceneFinitePlane.cpp:18-80).  Objects are listed in Scene index order;
+ * that order is observable (nearest-hit ties, per-light clamp order). */
+typedef struct rt_object_desc {
+    int32_t kind;                 /* RT_KIND_*                                 */
+    int32_t is_light;             /* SceneObject::isaLightSource               */
+    int32_t texture;              /* index into rt_scene_desc.textures, -1 none */
+    float   intensity;            /* SceneObject::intensity                    */
+    float   origin[3];            /* SceneObject::origin (sphere centre, light position, infinite-plane origin) */
+    float   color[3];             /* ObjMaterial::myColor                      */
+    float   diffuse, specular, reflective;
+    float   radius, radius_squared;               /* sphere                    */
+    float   plane_origin[3];                      /* finite plane              */
+    float   normal[3], vertical[3], horizontal[3], reverse_normal[3]; /* planes */
+    float   v_distance, h_distance;               /* finite plane              */
+    float   distance_to_origin;                   /* planes                    */
+} rt_object_desc;
+
+/* Texture_CheckerBoard (src/Texture_CheckerBoard.h:13-71): the only texture
+ * the reference has. */
+typedef struct rt_texture_desc {
+    float light[3], dark[3];
+    float width, height;
+} rt_texture_desc;
+
+typedef struct rt_scene_desc {
+    int32_t               n_objects;
+    const rt_object_desc *objects;
+    int32_t               n_textures;
+    const rt_texture_desc *textures;
+    /* Scene::scene_object_start_index / final_index (src/Scene.h:41-42): on
+     * x86 the shadow scan covers [shadow_begin, shadow_end)
+     * (src/RayTracer.cpp:716-722).  Scene::initialize() sets [0, count). */
+    int32_t               shadow_begin, shadow_end;
+    float                 null_color[3];   /* NULL_COLOR, src/RayTracer.h:52 */
+} rt_scene_desc;
+
+/* The members of Camera that createEyeRay reads (src/Camera.cpp:71-84). */
+typedef struct rt_camera_desc {
+    float screen_width, screen_height, screen_halfwidth, screen_halfheight;
+    float screen_origin[3], vector_horizontal[3], vector_vertical[3], eye_origin[3];
+} rt_camera_desc;
+
+typedef struct rt_scene rt_scene;     /* opaque; owns device copies of the tables */
+
+typedef struct rt_timing {
+    double   last_kernel_ms;    /* render kernel of the last rt_render* call (HIP events on its stream) */
+    double   sum_kernel_ms;     /* accumulated since rt_reset_timing                                    */
+    uint64_t launches;          /* kernel launches accumulated                                          */
+    double   last_upload_ms;    /* scene-table upload in rt_scene_create                                */
+    double   last_download_ms;  /* device->host copy in rt_render (0 for rt_render_device)              */
+} rt_timing;
+
+typedef struct rt_launch_info {
+    int32_t block_threads;      /* threads per workgroup                                        */
+    int32_t lds_bytes;          /* dynamic LDS per workgroup (scene tables + bounce stack)      */
+    int32_t scene_lds_bytes;    /* of which scene tables                                        */
+    int32_t grid_blocks;        /* workgroups of the last launch                                */
+    int32_t tile_x, tile_z;     /* pixels per wavefront tile (tile_x * tile_z == 64)            */
+} rt_launch_info;
+
+/* Replaces: the Scene the reference keeps in the global my_scene
+ * (src/RayTracer.h:50) -- copies the description, uploads the tables to
+ * `device`.  The caller keeps ownership of *desc. */
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+int rt_scene_destroy(rt_scene *scene);
+
+/* Replaces: raytrace_main()'s pixel loop (src/RayTracer.cpp:904-923) for
+ * columns [x0, x1) and all z of a W x H image, recursion limit max_depth
+ * (MAX_RECURSION_LEVEL, src/rt_project_parameters.h:73).  out_rgb is HOST
+ * memory, packed fp32: out_rgb[((x-x0)*H + z)*3 + c] -- the pixels[x][z]
+ * order of src/RayTracer.h:44.  dx = (float)x / W, dz = (float)z / H use the
+ * global W, H, so a strip is bit-identical to the same columns of a full
+ * render.  Synchronous. */
+int rt_render(rt_scene *scene, const rt_camera_desc *cam, int W, int H,
+              int x0, int x1, int max_depth, float *out_rgb);
+
+/* Same, but d_out_rgb is DEVICE memory on the scene's device and the kernel
+ * is enqueued on hip_stream (a hipStream_t; NULL = the null stream) without
+ * synchronising.  Used by the multi-GPU path and by callers that keep the
+ * framebuffer in HBM. */
+int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, int W, int H,
+                     int x0, int x1, int max_depth, void *d_out_rgb, void *hip_stream);
+
+/* Replaces: the reference's static partitioning (strategy 1,
+ * src/RayTracer.cpp:904-923 with CORE_NUM > 1) across the GPUs of one node,
+ * single process: contiguous x-strips, one per GPU, gathered to device 0 with
+ * ncclGather over xGMI, then copied to out_rgb (host, whole image). */
+int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
+                    int max_depth, int ngpu, float *out_rgb);
+
+int rt_get_timing(const rt_scene *scene, rt_timing *out);
+int rt_reset_timing(rt_scene *scene);
+int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
+
+/* Tuning knobs (speed only, never results).  key: "tile_z" (wavefront tile
+ * height: 1,2,4,...,64), "block_threads" (0 = auto, else 64..1024). */
+int rt_set_option(rt_scene *scene, const char *key, int value);
+
+int         rt_device_count(int *count);
+int         rt_capi_version(void);
+const char *rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_CAPI_H_ */

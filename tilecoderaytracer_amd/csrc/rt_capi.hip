@@ -1,0 +1,476 @@
+/*
+ * rt_capi.hip -- implementation of the C ABI in include/rt_capi.h:
+ * packs an rt_scene_desc into the device scene format (rt_tables.h), uploads
+ * it, launches rt_render_kernel and times it with HIP events on the launch
+ * stream.  No CPU rendering path exists here: without a HIP device every
+ * entry point that needs one fails.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_capi.h"
+#include "rt_tables.h"
+
+extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__restrict__ image,
+                                            const RtRun *__restrict__ runs,
+                                            const RtRun *__restrict__ shadow_runs, float *__restrict__ out);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorNoDevice ? RT_ERR_NO_DEVICE : RT_ERR_HIP,               \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+struct Quad { float v[4]; };
+
+float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+struct EventPair { hipEvent_t start, stop; bool pending; };
+constexpr int kEventRing = 64;
+
+} // namespace
+
+struct rt_scene {
+    int device = 0;
+    /* host copies */
+    std::vector<Quad> image;
+    std::vector<RtRun> runs, shadow_runs;
+    RtParams base{};              /* table offsets filled at create */
+    /* device copies */
+    void *d_image = nullptr, *d_runs = nullptr, *d_shadow_runs = nullptr;
+    /* scratch framebuffer for rt_render (host destination) */
+    void *d_fb = nullptr;
+    size_t d_fb_bytes = 0;
+    /* options */
+    int tile_z_log2 = 4;          /* 4 columns x 16 rows per wavefront */
+    int block_threads_opt = 0;    /* 0 = auto */
+    /* timing */
+    EventPair ev[kEventRing];
+    int ev_next = 0;
+    bool ev_ready = false;
+    rt_timing timing{};
+    rt_launch_info launch{};
+    std::mutex mu;
+};
+
+namespace {
+
+bool finite3(const float *v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+/* Build the LDS image + run lists from the description. */
+int pack_scene(const rt_scene_desc *desc, rt_scene *s) {
+    const int n = desc->n_objects;
+    if (n < 0) return fail(RT_ERR_INVALID, "n_objects < 0");
+    if (n > 0 && !desc->objects) return fail(RT_ERR_INVALID, "objects is NULL");
+    if (desc->n_textures < 0 || (desc->n_textures > 0 && !desc->textures))
+        return fail(RT_ERR_INVALID, "bad textures");
+    if (desc->shadow_begin < 0 || desc->shadow_end < desc->shadow_begin || desc->shadow_end > n)
+        return fail(RT_ERR_INVALID, "shadow range must satisfy 0 <= begin <= end <= n_objects");
+    (void)finite3;
+
+    std::vector<Quad> geom, lights, mats, texs;
+    std::vector<uint32_t> objinfo((size_t)n, 0u);
+    std::vector<int> geom_off((size_t)n, 0);
+    std::map<std::vector<uint32_t>, int> mat_index;
+
+    for (int i = 0; i < n; ++i) {
+        const rt_object_desc &o = desc->objects[i];
+        if (o.kind != RT_KIND_SPHERE && o.kind != RT_KIND_INFINITE_PLANE && o.kind != RT_KIND_FINITE_PLANE)
+            return fail(RT_ERR_INVALID, "object " + std::to_string(i) + ": unknown kind");
+        if (o.texture < -1 || o.texture >= desc->n_textures)
+            return fail(RT_ERR_INVALID, "object " + std::to_string(i) + ": texture index out of range");
+        geom_off[(size_t)i] = (int)geom.size();
+        if (o.kind == RT_KIND_SPHERE) {
+            geom.push_back({{o.origin[0], o.origin[1], o.origin[2], o.radius_squared}});
+        } else {
+            const float *anchor = (o.kind == RT_KIND_INFINITE_PLANE) ? o.origin : o.plane_origin;
+            geom.push_back({{o.normal[0], o.normal[1], o.normal[2], o.distance_to_origin}});
+            geom.push_back({{anchor[0], anchor[1], anchor[2], o.h_distance}});
+            geom.push_back({{o.horizontal[0], o.horizontal[1], o.horizontal[2], o.v_distance}});
+            geom.push_back({{o.vertical[0], o.vertical[1], o.vertical[2], 0.0f}});
+            geom.push_back({{o.reverse_normal[0], o.reverse_normal[1], o.reverse_normal[2], 0.0f}});
+        }
+        if (geom.size() > RT_MAX_GEOM_QUADS) return fail(RT_ERR_CAPACITY, "geometry table too large");
+
+        /* material row, de-duplicated bit-wise */
+        const uint32_t mbits = (o.is_light ? 1u : 0u) | ((uint32_t)(o.texture + 1) << 1);
+        Quad m0 = {{o.color[0], o.color[1], o.color[2], o.diffuse}};
+        Quad m1 = {{o.specular, o.reflective, o.intensity, bits_to_float(mbits)}};
+        std::vector<uint32_t> key(8);
+        std::memcpy(key.data(), m0.v, 16);
+        std::memcpy(key.data() + 4, m1.v, 16);
+        auto it = mat_index.find(key);
+        int mi;
+        if (it == mat_index.end()) {
+            mi = (int)mat_index.size();
+            if (mi > RT_MAX_MATERIALS) return fail(RT_ERR_CAPACITY, "too many distinct materials");
+            mat_index.emplace(key, mi);
+            mats.push_back(m0);
+            mats.push_back(m1);
+        } else {
+            mi = it->second;
+        }
+        objinfo[(size_t)i] = (uint32_t)geom_off[(size_t)i] | ((uint32_t)o.kind << 16) | ((uint32_t)mi << 20);
+
+        if (o.is_light) {
+            lights.push_back({{o.origin[0], o.origin[1], o.origin[2], o.intensity}});
+            lights.push_back({{o.color[0], o.color[1], o.color[2], bits_to_float((uint32_t)i)}});
+        }
+    }
+    for (int t = 0; t < desc->n_textures; ++t) {
+        const rt_texture_desc &x = desc->textures[t];
+        texs.push_back({{x.light[0], x.light[1], x.light[2], x.width}});
+        texs.push_back({{x.dark[0], x.dark[1], x.dark[2], x.height}});
+    }
+
+    /* runs: consecutive objects of one kind and one light flag, in index order */
+    auto build_runs = [&](int begin, int end, bool skip_lights, std::vector<RtRun> &out) {
+        out.clear();
+        for (int i = begin; i < end; ++i) {
+            const rt_object_desc &o = desc->objects[i];
+            if (skip_lights && o.is_light) continue;
+            if (!out.empty()) {
+                RtRun &b = out.back();
+                const rt_object_desc &prev = desc->objects[b.first + b.count - 1];
+                if (b.kind == o.kind && b.first + b.count == i && (prev.is_light != 0) == (o.is_light != 0)) {
+                    ++b.count;
+                    continue;
+                }
+            }
+            out.push_back(RtRun{o.kind, 1, i, geom_off[(size_t)i]});
+        }
+    };
+    build_runs(0, n, false, s->runs);
+    build_runs(desc->shadow_begin, desc->shadow_end, true, s->shadow_runs);
+
+    /* assemble the image */
+    RtParams &b = s->base;
+    std::memset(&b, 0, sizeof(b));
+    s->image.clear();
+    s->image.insert(s->image.end(), geom.begin(), geom.end());
+    b.lights_off = (int)s->image.size();
+    s->image.insert(s->image.end(), lights.begin(), lights.end());
+    b.mat_off = (int)s->image.size();
+    s->image.insert(s->image.end(), mats.begin(), mats.end());
+    b.tex_off = (int)s->image.size();
+    s->image.insert(s->image.end(), texs.begin(), texs.end());
+    b.objinfo_off = (int)s->image.size();
+    const size_t info_quads = ((size_t)n + 3) / 4;
+    s->image.resize(s->image.size() + info_quads, Quad{{0, 0, 0, 0}});
+    if (n > 0) std::memcpy(s->image[(size_t)b.objinfo_off].v, objinfo.data(), (size_t)n * 4);
+    if (s->image.empty()) s->image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
+    b.image_quads = (int)s->image.size();
+    b.n_runs = (int)s->runs.size();
+    b.n_shadow_runs = (int)s->shadow_runs.size();
+    b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
+    for (int c = 0; c < 3; ++c) b.null_color[c] = desc->null_color[c];
+    if ((size_t)b.image_quads * 16 + 64 * RT_STACK_ENTRY_BYTES > RT_MAX_LDS_BYTES)
+        return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
+    return RT_OK;
+}
+
+int ensure_events(rt_scene *s) {
+    if (s->ev_ready) return RT_OK;
+    for (int i = 0; i < kEventRing; ++i) {
+        HIP_TRY(hipEventCreate(&s->ev[i].start));
+        HIP_TRY(hipEventCreate(&s->ev[i].stop));
+        s->ev[i].pending = false;
+    }
+    s->ev_ready = true;
+    return RT_OK;
+}
+
+int drain_event(rt_scene *s, int i) {
+    EventPair &e = s->ev[i];
+    if (!e.pending) return RT_OK;
+    HIP_TRY(hipEventSynchronize(e.stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e.start, e.stop));
+    s->timing.last_kernel_ms = ms;
+    s->timing.sum_kernel_ms += ms;
+    s->timing.launches += 1;
+    e.pending = false;
+    return RT_OK;
+}
+
+/* choose the workgroup size so tables + bounce stack fit in LDS */
+int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes) {
+    const size_t scene_bytes = (size_t)s->base.image_quads * 16;
+    const size_t per_thread = (size_t)RT_STACK_ENTRY_BYTES * (size_t)(max_depth + 1);
+    const int candidates[3] = {256, 128, 64};
+    if (s->block_threads_opt) {
+        const size_t need = scene_bytes + per_thread * (size_t)s->block_threads_opt;
+        if (need > RT_MAX_LDS_BYTES)
+            return fail(RT_ERR_CAPACITY, "block_threads option: tables + bounce stack exceed 160 KiB LDS");
+        *block = s->block_threads_opt; *lds_bytes = (int)need;
+        return RT_OK;
+    }
+    /* prefer the largest workgroup that still leaves room for two per CU,
+     * else the largest that fits at all */
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t limit = pass == 0 ? RT_MAX_LDS_BYTES / 2 : RT_MAX_LDS_BYTES;
+        for (int c : candidates) {
+            const size_t need = scene_bytes + per_thread * (size_t)c;
+            if (need <= limit) { *block = c; *lds_bytes = (int)need; return RT_OK; }
+        }
+    }
+    return fail(RT_ERR_CAPACITY, "max_depth too large: scene tables + bounce stack exceed 160 KiB LDS");
+}
+
+int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
+           float *d_out, hipStream_t stream) {
+    if (!cam) return fail(RT_ERR_INVALID, "camera is NULL");
+    if (W <= 0 || H <= 0) return fail(RT_ERR_INVALID, "W and H must be positive");
+    if (x0 < 0 || x1 > W || x0 > x1) return fail(RT_ERR_INVALID, "need 0 <= x0 <= x1 <= W");
+    if (max_depth < 0) return fail(RT_ERR_INVALID, "max_depth < 0");
+    if (!d_out && x1 > x0) return fail(RT_ERR_INVALID, "output pointer is NULL");
+    if ((double)(x1 - x0) * (double)H * 3.0 > 2.0e9 * 4.0)
+        return fail(RT_ERR_INVALID, "strip too large");
+
+    int block = 0, lds_bytes = 0;
+    int rc = choose_block(s, max_depth, &block, &lds_bytes);
+    if (rc) return rc;
+
+    RtParams p = s->base;
+    for (int c = 0; c < 3; ++c) {
+        p.so[c] = cam->screen_origin[c];
+        p.ch[c] = cam->vector_horizontal[c];
+        p.cv[c] = cam->vector_vertical[c];
+        p.eye[c] = cam->eye_origin[c];
+    }
+    p.sw = cam->screen_width; p.sh = cam->screen_height;
+    p.shw = cam->screen_halfwidth; p.shh = cam->screen_halfheight;
+    p.W = W; p.H = H; p.x0 = x0; p.x1 = x1; p.max_depth = max_depth;
+    p.tile_z_log2 = s->tile_z_log2;
+    const int tile_z = 1 << s->tile_z_log2, tile_x = 64 >> s->tile_z_log2;
+    const long long tiles_z = ((long long)H + tile_z - 1) / tile_z;
+    const long long tiles_x = ((long long)(x1 - x0) + tile_x - 1) / tile_x;
+    const long long n_tiles = tiles_z * tiles_x;
+    if (n_tiles > 0x7fffffffLL) return fail(RT_ERR_INVALID, "too many tiles");
+    p.tiles_z = (int)tiles_z;
+    p.n_tiles = (int)n_tiles;
+    const int waves_per_block = block / 64;
+    const long long blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
+
+    s->launch.block_threads = block;
+    s->launch.lds_bytes = lds_bytes;
+    s->launch.scene_lds_bytes = s->base.image_quads * 16;
+    s->launch.grid_blocks = (int)blocks;
+    s->launch.tile_x = tile_x;
+    s->launch.tile_z = tile_z;
+    if (blocks == 0) return RT_OK;
+
+    HIP_TRY(hipSetDevice(s->device));
+    rc = ensure_events(s);
+    if (rc) return rc;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    const int slot = s->ev_next;
+    rc = drain_event(s, slot);            /* ring wrapped: account for the old launch first */
+    if (rc) return rc;
+    s->ev_next = (s->ev_next + 1) % kEventRing;
+    HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
+    hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
+                       p, reinterpret_cast<const float4 *>(s->d_image),
+                       reinterpret_cast<const RtRun *>(s->d_runs),
+                       reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
+    s->ev[slot].pending = true;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+/* used by rt_multi.hip to report through rt_last_error() */
+int rt_internal_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+
+int rt_capi_version(void) { return RT_CAPI_VERSION; }
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_device_count(int *count) {
+    if (!count) return fail(RT_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(RT_ERR_NO_DEVICE, hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
+    if (!desc || !out) return fail(RT_ERR_INVALID, "desc/out is NULL");
+    *out = nullptr;
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_INVALID, "out of memory");
+    int rc = pack_scene(desc, s);
+    if (rc) { delete s; return rc; }
+    s->device = device;
+    auto bail = [&](int code) { rt_scene_destroy(s); return code; };
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return bail(fail(RT_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)"));
+    if (device < 0 || device >= ndev) return bail(fail(RT_ERR_INVALID, "device index out of range"));
+#define HIP_TRY_B(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return bail(fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+    HIP_TRY_B(hipSetDevice(device));
+    hipEvent_t t0, t1;
+    HIP_TRY_B(hipEventCreate(&t0));
+    HIP_TRY_B(hipEventCreate(&t1));
+    HIP_TRY_B(hipEventRecord(t0, nullptr));
+    const size_t image_bytes = s->image.size() * sizeof(Quad);
+    const size_t run_bytes = (s->runs.size() + 1) * sizeof(RtRun);
+    const size_t srun_bytes = (s->shadow_runs.size() + 1) * sizeof(RtRun);
+    HIP_TRY_B(hipMalloc(&s->d_image, image_bytes));
+    HIP_TRY_B(hipMalloc(&s->d_runs, run_bytes));
+    HIP_TRY_B(hipMalloc(&s->d_shadow_runs, srun_bytes));
+    HIP_TRY_B(hipMemcpy(s->d_image, s->image.data(), image_bytes, hipMemcpyHostToDevice));
+    if (!s->runs.empty())
+        HIP_TRY_B(hipMemcpy(s->d_runs, s->runs.data(), s->runs.size() * sizeof(RtRun), hipMemcpyHostToDevice));
+    if (!s->shadow_runs.empty())
+        HIP_TRY_B(hipMemcpy(s->d_shadow_runs, s->shadow_runs.data(), s->shadow_runs.size() * sizeof(RtRun),
+                            hipMemcpyHostToDevice));
+    HIP_TRY_B(hipEventRecord(t1, nullptr));
+    HIP_TRY_B(hipEventSynchronize(t1));
+    float ms = 0.f;
+    HIP_TRY_B(hipEventElapsedTime(&ms, t0, t1));
+    s->timing.last_upload_ms = ms;
+    hipEventDestroy(t0);
+    hipEventDestroy(t1);
+#undef HIP_TRY_B
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene *s) {
+    if (!s) return RT_OK;
+    if (s->d_image || s->d_fb || s->ev_ready) (void)hipSetDevice(s->device);
+    if (s->ev_ready)
+        for (int i = 0; i < kEventRing; ++i) { hipEventDestroy(s->ev[i].start); hipEventDestroy(s->ev[i].stop); }
+    if (s->d_image) hipFree(s->d_image);
+    if (s->d_runs) hipFree(s->d_runs);
+    if (s->d_shadow_runs) hipFree(s->d_shadow_runs);
+    if (s->d_fb) hipFree(s->d_fb);
+    delete s;
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
+                     void *d_out_rgb, void *hip_stream) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    return launch(s, cam, W, H, x0, x1, max_depth, static_cast<float *>(d_out_rgb),
+                  static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_render(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
+              float *out_rgb) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1) return fail(RT_ERR_INVALID, "need 0 <= x0 <= x1 <= W, W,H > 0");
+    const size_t bytes = (size_t)(x1 - x0) * (size_t)H * 3 * sizeof(float);
+    if (bytes && !out_rgb) return fail(RT_ERR_INVALID, "out_rgb is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    if (bytes > s->d_fb_bytes) {
+        if (s->d_fb) { HIP_TRY(hipFree(s->d_fb)); s->d_fb = nullptr; s->d_fb_bytes = 0; }
+        HIP_TRY(hipMalloc(&s->d_fb, bytes));
+        s->d_fb_bytes = bytes;
+    }
+    int rc = launch(s, cam, W, H, x0, x1, max_depth, static_cast<float *>(s->d_fb), nullptr);
+    if (rc) return rc;
+    s->timing.last_download_ms = 0.0;
+    if (bytes) {
+        hipEvent_t t0, t1;
+        HIP_TRY(hipEventCreate(&t0));
+        HIP_TRY(hipEventCreate(&t1));
+        HIP_TRY(hipEventRecord(t0, nullptr));
+        HIP_TRY(hipMemcpy(out_rgb, s->d_fb, bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipEventRecord(t1, nullptr));
+        HIP_TRY(hipEventSynchronize(t1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+        s->timing.last_download_ms = ms;
+        hipEventDestroy(t0);
+        hipEventDestroy(t1);
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return RT_OK;
+}
+
+int rt_get_timing(const rt_scene *cs, rt_timing *out) {
+    if (!cs || !out) return fail(RT_ERR_INVALID, "scene/out is NULL");
+    rt_scene *s = const_cast<rt_scene *>(cs);
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->ev_ready) {
+        HIP_TRY(hipSetDevice(s->device));
+        /* drain in launch order so last_kernel_ms is the newest launch */
+        for (int k = 0; k < kEventRing; ++k) {
+            int rc = drain_event(s, (s->ev_next + k) % kEventRing);
+            if (rc) return rc;
+        }
+    }
+    *out = s->timing;
+    return RT_OK;
+}
+
+int rt_reset_timing(rt_scene *s) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    rt_timing t;
+    int rc = rt_get_timing(s, &t);        /* drains pending events */
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->timing.sum_kernel_ms = 0.0;
+    s->timing.launches = 0;
+    return RT_OK;
+}
+
+int rt_get_launch_info(const rt_scene *s, rt_launch_info *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "scene/out is NULL");
+    *out = s->launch;
+    out->scene_lds_bytes = s->base.image_quads * 16;
+    return RT_OK;
+}
+
+int rt_set_option(rt_scene *s, const char *key, int value) {
+    if (!s || !key) return fail(RT_ERR_INVALID, "scene/key is NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!std::strcmp(key, "tile_z")) {
+        int lg = -1;
+        for (int i = 0; i <= 6; ++i) if ((1 << i) == value) lg = i;
+        if (lg < 0) return fail(RT_ERR_INVALID, "tile_z must be a power of two in [1, 64]");
+        s->tile_z_log2 = lg;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "block_threads")) {
+        if (value != 0 && (value < 64 || value > 256 || (value % 64) != 0))
+            return fail(RT_ERR_INVALID, "block_threads must be 0 (auto), 64, 128, 192 or 256");
+        s->block_threads_opt = value;
+        return RT_OK;
+    }
+    return fail(RT_ERR_INVALID, std::string("unknown option: ") + key);
+}
+
+} // extern "C"

@@ -1,0 +1,373 @@
+/*
+ * rt_kernel.hip -- the render kernel for gfx950 (MI355X).
+ *
+ * One wavefront lane per pixel.  Restates, for the GPU, the hot path of
+ * ccelio/TileCodeRayTracer: raytrace_main's pixel loop
+ * (src/RayTracer.cpp:904-923) -> Camera::createEyeRay (src/Camera.cpp:71-84)
+ * -> calculatePixel (src/RayTracer.cpp:448-638) -> getCollision (:50-89),
+ * inShade (:709-771), cosineShade (:654-701), the three collision() routines
+ * and the CollisionObject constructor (src/SceneObject.h:47-105).
+ *
+ * What is different from the reference, and why it is still bit-identical:
+ *  - The reference builds a full hit record for EVERY candidate object; only
+ *    `distance` takes part in choosing the nearest hit / the shadow verdict.
+ *    Here every candidate yields a distance only, and the record (point,
+ *    normal, colour, reflected ray) is built once, for the winner, with the
+ *    same operations in the same order.
+ *  - The recursion `final_k = local_k + (rf_k * C_{k+1}) * oc_k`
+ *    (src/RayTracer.cpp:601) is flattened: a forward loop over bounce levels
+ *    pushes {local_k, object} on a per-lane stack in LDS, a backward loop
+ *    combines inside-out, so the association order is the reference's.
+ *  - The object list is walked as runs of one primitive kind (rt_tables.h) in
+ *    Scene index order; the loop counters are wave-uniform, the tables are read
+ *    from LDS with the same address in every lane (a broadcast, no conflicts).
+ *
+ * Arithmetic contract: IEEE-754 binary32, no FMA contraction
+ * (-ffp-contract=off and the pragma below), correctly rounded '/' and sqrtf
+ * (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt), denormals kept,
+ * exact fmodf.  Never build this file with -ffast-math.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_tables.h"
+
+#pragma clang fp contract(off)
+
+#define RT_KIND_SPHERE 0
+#define RT_KIND_INFINITE_PLANE 1
+#define RT_KIND_FINITE_PLANE 2
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 xyz(const float4 q) { return mk(q.x, q.y, q.z); }
+/* vector3d operators, src/vector3d.h:97-124 -- association order is part of the contract */
+__device__ __forceinline__ float dot3(const V3 a, const V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 sub3(const V3 a, const V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 add3(const V3 a, const V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 scale3(const V3 v, const float f) { return mk(v.x * f, v.y * f, v.z * f); }
+/* vector3d::normalize, src/vector3d.h:55-73: sqrtf then three true divides */
+__device__ __forceinline__ V3 normalize3(const V3 v) {
+    const float length = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return mk(v.x / length, v.y / length, v.z / length);
+}
+
+/* SceneSphere::collision reduced to its distance, src/SceneSphere.cpp:50-116.
+ * Returns true when the reference would return a CollisionObject; *dist is
+ * then the distance it reports (v - sqrt(d^2), negative for inside hits). */
+__device__ __forceinline__ bool sphere_distance(const float4 s, const V3 o, const V3 d, float *dist) {
+    const V3 OE = mk(s.x - o.x, s.y - o.y, s.z - o.z);
+    const float v = dot3(OE, d);
+    if (v < (float)0) return false;
+    const float d_squared = s.w - (dot3(OE, OE) - v * v);
+    if (d_squared < (float)1E-9) return false;
+    const float sq = sqrtf(d_squared);
+    const float root1 = v - sq;
+    const float root2 = v + sq;
+    if (root2 > (float)0) {
+        if (root1 < (float)0) {
+            if (!(root2 < 65535.0f)) return false;
+        } else {
+            if (!(root1 < 65535.0f)) return false;
+        }
+    } else {
+        return false;
+    }
+    *dist = root1;
+    return true;
+}
+
+/* SceneInfinitePlane::collision reduced to t, src/SceneInfinitePlane.cpp:29-51 */
+__device__ __forceinline__ bool infinite_plane_distance(const float4 q0, const V3 o, const V3 d, float *dist) {
+    const V3 n = xyz(q0);
+    const float numerator = -q0.w - dot3(o, n);
+    const float denom = dot3(d, n);
+    if (denom == (float)0) return false;
+    const float t = numerator / denom;
+    if (t < (float)1E-10) return false;
+    *dist = t;
+    return true;
+}
+
+/* SceneFinitePlane::collision reduced to t, src/SceneFinitePlane.cpp:86-124 */
+__device__ __forceinline__ bool finite_plane_distance(const float4 *g, const V3 o, const V3 d, float *dist) {
+    const float4 q0 = g[0];
+    const V3 n = xyz(q0);
+    const float numerator = -q0.w - dot3(o, n);
+    const float denom = dot3(d, n);
+    if (denom == 0) return false;
+    const float t = numerator / denom;
+    if ((double)t < 1E-5) return false;          /* the reference compares in double, :102 */
+    const float4 q1 = g[1], q2 = g[2], q3 = g[3];
+    const V3 p = add3(scale3(d, t), o);
+    const V3 PO = sub3(p, xyz(q1));
+    const float x = dot3(PO, xyz(q2));
+    const float y = dot3(PO, xyz(q3));
+    if (x < 0 || x > q1.w || y < 0 || y > q2.w) return false;
+    *dist = t;
+    return true;
+}
+
+/* getCollision, src/RayTracer.cpp:50-89: first strictly-smaller distance in
+ * Scene index order wins; "infinity" is 65535. */
+__device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__restrict__ runs,
+                                            const float4 *lds, const V3 o, const V3 d,
+                                            float *best_out, int *best_idx_out) {
+    float best = 65535.0f;
+    int best_idx = -1;
+    for (int r = 0; r < p.n_runs; ++r) {
+        const RtRun run = runs[r];
+        const float4 *g = lds + run.geom_off;
+        if (run.kind == RT_KIND_SPHERE) {
+            for (int i = 0; i < run.count; ++i) {
+                float t;
+                if (sphere_distance(g[i], o, d, &t) && t < best) { best = t; best_idx = run.first + i; }
+            }
+        } else if (run.kind == RT_KIND_INFINITE_PLANE) {
+            for (int i = 0; i < run.count; ++i) {
+                float t;
+                if (infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, &t) && t < best) {
+                    best = t; best_idx = run.first + i;
+                }
+            }
+        } else {
+            for (int i = 0; i < run.count; ++i) {
+                float t;
+                if (finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, &t) && t < best) {
+                    best = t; best_idx = run.first + i;
+                }
+            }
+        }
+    }
+    *best_out = best;
+    *best_idx_out = best_idx;
+}
+
+/* inShadeCollisionDetection, src/RayTracer.cpp:709-739: any non-light object
+ * of the scan range with distance < dist_to_light blocks.  A boolean OR, so
+ * the scan order is free; lanes drop out as soon as they are blocked. */
+__device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restrict__ shadow_runs,
+                                         const float4 *lds, const V3 o, const V3 d, const float dist_to_light) {
+    bool blocked = false;
+    for (int r = 0; r < p.n_shadow_runs && !blocked; ++r) {
+        const RtRun run = shadow_runs[r];
+        const float4 *g = lds + run.geom_off;
+        if (run.kind == RT_KIND_SPHERE) {
+            for (int i = 0; i < run.count && !blocked; ++i) {
+                float t;
+                if (sphere_distance(g[i], o, d, &t) && t < dist_to_light) blocked = true;
+            }
+        } else if (run.kind == RT_KIND_INFINITE_PLANE) {
+            for (int i = 0; i < run.count && !blocked; ++i) {
+                float t;
+                if (infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, &t) && t < dist_to_light) blocked = true;
+            }
+        } else {
+            for (int i = 0; i < run.count && !blocked; ++i) {
+                float t;
+                if (finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, &t) && t < dist_to_light) blocked = true;
+            }
+        }
+    }
+    return blocked;
+}
+
+/* Texture_CheckerBoard::getTexturePixel, src/Texture_CheckerBoard.h:31-65.
+ * Returns 1 for the light colour, 2 for the dark colour. */
+__device__ __forceinline__ int checkerboard_select(const float width, const float height, float x, float y) {
+    if (x >= 0) x = fmodf(x, width);
+    else        x = fmodf((fmodf((-x), width) + width / 2.0f), width);
+    if (y >= 0) y = fmodf(y, height);
+    else        y = fmodf((fmodf((-y), height) + height / 2.0f), height);
+    if (x < width / 2) return (y < height / 2) ? 1 : 2;
+    return (y < height / 2) ? 2 : 1;
+}
+
+/* colour of a stack entry / hit: material colour, or one of the texture's two */
+__device__ __forceinline__ V3 entry_colour(const RtParams &p, const float4 *lds, const float4 m0,
+                                           const uint32_t mbits, const int texsel) {
+    if (texsel == 0) return xyz(m0);
+    const int tex = (int)(mbits >> 1) - 1;
+    return xyz(lds[p.tex_off + tex * RT_TEX_QUADS + (texsel - 1)]);
+}
+
+} // namespace
+
+extern "C" __global__ void __launch_bounds__(256)
+rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
+                 const RtRun *__restrict__ shadow_runs, float *__restrict__ out) {
+    extern __shared__ float4 lds[];
+
+    /* stage the scene tables: global -> LDS, once per workgroup */
+    for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
+    __syncthreads();
+
+    float4 *stack = lds + p.image_quads;          /* [level][threadIdx.x] */
+    const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
+
+    /* pixel of this lane: wavefront tiles are tile_x columns by tile_z rows;
+     * consecutive lanes walk z, the contiguous axis of pixels[x][z] */
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int tile_col = wave / p.tiles_z;
+    const int tile_row = wave - tile_col * p.tiles_z;
+    const int tz = 1 << p.tile_z_log2;
+    const int x = p.x0 + tile_col * (64 >> p.tile_z_log2) + (lane >> p.tile_z_log2);
+    const int z = tile_row * tz + (lane & (tz - 1));
+    const bool inside = (wave < p.n_tiles) && (x < p.x1) && (z < p.H);
+
+    /* Camera::createEyeRay, src/Camera.cpp:71-84, with dx = (float)x / W,
+     * dz = (float)z / H from the pixel loop, src/RayTracer.cpp:916-918 */
+    V3 o = mk(p.eye[0], p.eye[1], p.eye[2]);
+    V3 d;
+    {
+        const float dx_percent = ((float)x) / (float)p.W;
+        const float dy_percent = ((float)z) / (float)p.H;
+        const float scalar_x = dx_percent * p.sw - p.shw;
+        const float scalar_y = dy_percent * p.sh - p.shh;
+        V3 pixel = add3(mk(p.so[0], p.so[1], p.so[2]), scale3(mk(p.ch[0], p.ch[1], p.ch[2]), scalar_x));
+        pixel = add3(pixel, scale3(mk(p.cv[0], p.cv[1], p.cv[2]), scalar_y));
+        d = normalize3(sub3(pixel, o));
+    }
+
+    const V3 null_color = mk(p.null_color[0], p.null_color[1], p.null_color[2]);
+    V3 C = null_color;        /* value returned by the deepest calculatePixel call of this lane */
+    int top = 0;              /* reflective levels pushed by this lane */
+    int levels = 0;           /* wave-uniform: levels any lane entered */
+    bool alive = inside;
+
+    /* calculatePixel, src/RayTracer.cpp:448-638, levels 0..max_depth */
+    for (int level = 0; level <= p.max_depth; ++level) {
+        if (__ballot(alive) == 0ull) break;
+        levels = level + 1;
+        if (alive) {
+            float t;
+            int idx;
+            nearest_hit(p, runs, lds, o, d, &t, &idx);
+            if (idx < 0) {                                   /* :507-509 */
+                C = null_color;
+                alive = false;
+            } else {
+                /* ---- build the winner's CollisionObject ---- */
+                const uint32_t info = lds_u32[p.objinfo_off * 4 + idx];
+                const float4 *g = lds + (info & 0xFFFFu);
+                const int kind = (int)((info >> 16) & 3u);
+                const int mat = (int)(info >> 20);
+                const float4 m0 = lds[p.mat_off + mat * RT_MAT_QUADS];
+                const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
+                const uint32_t mbits = __float_as_uint(m1.w);
+                const float diffuse_factor = m0.w, specular_factor = m1.x, reflective_factor = m1.y;
+                V3 P, N;
+                int texsel = 0;
+                if (kind == RT_KIND_SPHERE) {                /* src/SceneSphere.cpp:118-149 */
+                    const float4 s = g[0];
+                    P = add3(scale3(d, t), o);
+                    N = normalize3(sub3(P, xyz(s)));
+                } else {                                     /* src/SceneInfinitePlane.cpp:53-95, src/SceneFinitePlane.cpp:106-150 */
+                    const float4 q0 = g[0], q1 = g[1], q2 = g[2], q3 = g[3], q4 = g[4];
+                    const V3 ip = add3(scale3(d, t), o);
+                    if ((mbits >> 1) != 0u) {
+                        const V3 PO = sub3(ip, xyz(q1));
+                        const float tx = dot3(PO, xyz(q2));
+                        const float ty = dot3(PO, xyz(q3));
+                        const int tex = (int)(mbits >> 1) - 1;
+                        const float4 t0 = lds[p.tex_off + tex * RT_TEX_QUADS];
+                        const float4 t1 = lds[p.tex_off + tex * RT_TEX_QUADS + 1];
+                        texsel = checkerboard_select(t0.w, t1.w, tx, ty);
+                    }
+                    N = (dot3(xyz(q0), d) < 0) ? xyz(q0) : xyz(q4);
+                    P = add3(ip, scale3(N, (float)1E-3));
+                }
+                const V3 object_color = entry_colour(p, lds, m0, mbits, texsel);
+
+                if (mbits & 1u) {                            /* hit a light: :520-527 */
+                    C = scale3(object_color, m1.z);
+                    alive = false;
+                } else {
+                    /* CollisionObject ctor, src/SceneObject.h:62-92 */
+                    const V3 normal_dir = normalize3(N);           /* Ray(point, normal) re-normalises */
+                    const float n_dot_incoming = dot3(N, d);
+                    V3 final_color = mk(0.0f, 0.0f, 0.0f);
+
+                    /* lights in Scene index order, :540-591 */
+                    for (int l = 0; l < p.n_lights; ++l) {
+                        const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
+                        const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
+                        /* inShade, :743-771 */
+                        const V3 dir = sub3(xyz(l0), P);
+                        const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+                        const V3 light_ray = normalize3(dir);      /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
+                        if (!in_shade(p, shadow_runs, lds, P, light_ray, dist_to_light)) {
+                            const V3 light_color = xyz(l1);
+                            /* cosineShade, :654-701 */
+                            if (diffuse_factor > (float)0) {
+                                float cosine_dot_factor = dot3(normal_dir, light_ray);
+                                if (cosine_dot_factor > (float)0) {
+                                    const float factor = cosine_dot_factor * diffuse_factor * l0.w;
+                                    final_color.x += factor * object_color.x * light_color.x;
+                                    final_color.y += factor * object_color.y * light_color.y;
+                                    final_color.z += factor * object_color.z * light_color.z;
+                                }
+                                final_color.x = (final_color.x > 1.0f) ? 1.0f : final_color.x;
+                                final_color.y = (final_color.y > 1.0f) ? 1.0f : final_color.y;
+                                final_color.z = (final_color.z > 1.0f) ? 1.0f : final_color.z;
+                            }
+                            /* specular, :561-588 */
+                            const V3 Nn = normalize3(normal_dir);  /* third normalisation, :566-567 */
+                            const V3 R = sub3(light_ray, scale3(Nn, 2.0f * dot3(light_ray, Nn)));
+                            const float dot = dot3(d, R);
+                            if (dot > (float)0) {
+                                float pow_factor = dot;
+#pragma unroll
+                                for (int j = 0; j < 19; ++j) pow_factor *= dot;
+                                const float spec_factor = pow_factor * specular_factor;
+                                final_color = add3(final_color, scale3(light_color, spec_factor));
+                            }
+                        }
+                    }
+
+                    if (reflective_factor > (float)0) {      /* :595-604 */
+                        const V3 reflected = mk(-2 * N.x * n_dot_incoming + d.x,
+                                                -2 * N.y * n_dot_incoming + d.y,
+                                                -2 * N.z * n_dot_incoming + d.z);
+                        float4 e;
+                        e.x = final_color.x; e.y = final_color.y; e.z = final_color.z;
+                        e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
+                        stack[level * blockDim.x + threadIdx.x] = e;
+                        top = level + 1;
+                        o = P;
+                        d = normalize3(reflected);           /* Ray(point, reflected) */
+                        /* if the loop ends now the call at max_depth+1 returns NULL_COLOR, :454-455 */
+                        C = null_color;
+                    } else {
+                        C = final_color;
+                        alive = false;
+                    }
+                }
+            }
+        }
+    }
+
+    /* unwind: final_k = local_k + (rf_k * C_{k+1}) * oc_k, inside-out (:601) */
+    for (int k = levels - 1; k >= 0; --k) {
+        if (k < top) {
+            const float4 e = stack[k * blockDim.x + threadIdx.x];
+            const uint32_t bits = __float_as_uint(e.w);
+            const uint32_t info = lds_u32[p.objinfo_off * 4 + (bits & 0xFFFFu)];
+            const int mat = (int)(info >> 20);
+            const float4 m0 = lds[p.mat_off + mat * RT_MAT_QUADS];
+            const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
+            const V3 oc = entry_colour(p, lds, m0, __float_as_uint(m1.w), (int)(bits >> 16));
+            const V3 refl = mk(C.x * m1.y * oc.x, C.y * m1.y * oc.y, C.z * m1.y * oc.z);
+            C = add3(mk(e.x, e.y, e.z), refl);
+        }
+    }
+
+    if (inside) {
+        float *dst = out + ((size_t)(x - p.x0) * (size_t)p.H + (size_t)z) * 3;
+        dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
+    }
+}

@@ -1,0 +1,74 @@
+/*
+ * rt_tables.h -- the device scene format: what rt_scene_create() packs from an
+ * rt_scene_desc and what every workgroup stages into LDS.
+ *
+ * The image is an array of 16-byte "quads" (float4).  Sections, in order:
+ *
+ *   geometry   one record per object, Scene index order
+ *                sphere          1 quad : {cx, cy, cz, r^2}
+ *                infinite plane  5 quads: q0 {n.xyz, distance_to_origin}
+ *                finite plane    5 quads  q1 {anchor.xyz, h_distance}
+ *                                         q2 {horizontal.xyz, v_distance}
+ *                                         q3 {vertical.xyz, 0}
+ *                                         q4 {reverseNormal.xyz, 0}
+ *                (anchor = SceneObject::origin for the infinite plane,
+ *                 plane_origin for the finite plane: the point texture/bounds
+ *                 coordinates are measured from)
+ *   lights     2 quads per light, Scene index order:
+ *                {origin.xyz, intensity}, {colour.rgb, bits(object index)}
+ *   materials  2 quads per DISTINCT (ObjMaterial, intensity, light flag) row:
+ *                {colour.rgb, diffuse}, {specular, reflective, intensity,
+ *                 bits(is_light | (texture+1) << 1)}
+ *   textures   2 quads per checkerboard: {light.rgb, width}, {dark.rgb, height}
+ *   objinfo    one u32 per object (4 per quad):
+ *                bits 0-15 geometry offset (quads), 16-17 kind, 20-31 material row
+ *
+ * The object list is additionally described as RUNS of consecutive objects of
+ * one kind and one light flag (an int4 each, kept in global memory and read
+ * with scalar loads because the run index is wave-uniform).  Runs preserve
+ * Scene index order, so "first strictly-smaller distance wins"
+ * (src/RayTracer.cpp:75-78) needs no tie-break logic.  A second run list holds
+ * the non-light objects inside the shadow scan range
+ * (src/RayTracer.cpp:716-729).
+ */
+#ifndef RT_TABLES_H_
+#define RT_TABLES_H_
+
+#include <stdint.h>
+
+#define RT_SPHERE_QUADS 1
+#define RT_PLANE_QUADS  5
+#define RT_LIGHT_QUADS  2
+#define RT_MAT_QUADS    2
+#define RT_TEX_QUADS    2
+
+#define RT_MAX_GEOM_QUADS 65535   /* 16-bit geometry offset in objinfo */
+#define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
+#define RT_MAX_LDS_BYTES  (160 * 1024)
+
+#define RT_STACK_ENTRY_BYTES 16   /* {local.rgb, bits(object index | texsel << 16)} per bounce level per lane */
+
+typedef struct RtRun {
+    int32_t kind;       /* RT_KIND_*                               */
+    int32_t count;      /* objects in the run                      */
+    int32_t first;      /* Scene index of the first object         */
+    int32_t geom_off;   /* quad offset of the first object's record */
+} RtRun;
+
+typedef struct RtParams {
+    /* camera (src/Camera.cpp:71-84) */
+    float so[3], ch[3], cv[3], eye[3];
+    float sw, sh, shw, shh;
+    float null_color[3];
+    int32_t W, H, x0, x1, max_depth;
+    /* tables */
+    int32_t n_runs, n_shadow_runs, n_lights;
+    int32_t image_quads;                 /* quads staged into LDS */
+    int32_t lights_off, mat_off, tex_off, objinfo_off;   /* quad offsets */
+    /* tiling: a wavefront renders tile_x x tile_z pixels, tile_x * tile_z == 64 */
+    int32_t tile_z_log2;
+    int32_t tiles_z;                     /* wavefront tiles along z */
+    int32_t n_tiles;                     /* total wavefront tiles   */
+} RtParams;
+
+#endif /* RT_TABLES_H_ */

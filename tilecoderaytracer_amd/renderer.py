@@ -1,0 +1,68 @@
+"""Convenience wrapper over the C ABI for tests and bench.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Renderer:
+    """Owns an ``rt_scene`` (device tables for one HostScene on one GPU)."""
+
+    def __init__(self, host_scene, device=0):
+        self._lib = capi.load_library()
+        self._host = host_scene          # keeps the desc arrays alive
+        self._scene = C.c_void_p()
+        capi.check(self._lib.rt_scene_create(host_scene.desc, device, C.byref(self._scene)))
+        self._cam = host_scene.camera
+
+    @classmethod
+    def from_desc(cls, desc, camera, device=0, keepalive=None):
+        """Build from raw RtSceneDesc / RtCameraDesc (tests with hand-made tables)."""
+        self = cls.__new__(cls)
+        self._lib = capi.load_library()
+        self._host = keepalive
+        self._scene = C.c_void_p()
+        capi.check(self._lib.rt_scene_create(C.byref(desc), device, C.byref(self._scene)))
+        self._cam = C.pointer(camera)
+        return self
+
+    def close(self):
+        if getattr(self, "_scene", None):
+            self._lib.rt_scene_destroy(self._scene)
+            self._scene = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        capi.check(self._lib.rt_set_option(self._scene, key.encode(), int(value)))
+
+    def render(self, W, H, max_depth, x0=0, x1=None):
+        """Columns [x0, x1) of a W x H image -> float32 array (x1-x0, H, 3)."""
+        x1 = W if x1 is None else x1
+        out = np.empty((max(x1 - x0, 0), H, 3), dtype=np.float32)
+        capi.check(self._lib.rt_render(self._scene, self._cam, W, H, x0, x1, max_depth,
+                                       out.ctypes.data))
+        return out
+
+    def render_device(self, W, H, max_depth, x0, x1, device_ptr, stream=0):
+        """Enqueue a render into device memory on a HIP stream (no sync)."""
+        capi.check(self._lib.rt_render_device(self._scene, self._cam, W, H, x0, x1, max_depth,
+                                              C.c_void_p(device_ptr), C.c_void_p(stream)))
+
+    def timing(self):
+        t = capi.RtTiming()
+        capi.check(self._lib.rt_get_timing(self._scene, C.byref(t)))
+        return t
+
+    def reset_timing(self):
+        capi.check(self._lib.rt_reset_timing(self._scene))
+
+    def launch_info(self):
+        li = capi.RtLaunchInfo()
+        capi.check(self._lib.rt_get_launch_info(self._scene, C.byref(li)))
+        return li
