@@ -1,0 +1,114 @@
+"""The C-ABI library loads, exports every symbol include/rt_capi.h declares,
+validates descriptions, and -- on a machine without a GPU -- refuses to render
+instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tilecoderaytracer_amd import HostScene, RtError, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rt_capi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:int|const char \*)\s*(rt_\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_functions()
+    for n in ("rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_multi",
+              "rt_last_error", "rt_get_timing"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_library()
+    for name in declared_functions():
+        assert getattr(lib, name) is not None, name
+    assert lib.rt_capi_version() == 1
+
+
+def test_struct_sizes_match_the_header():
+    # field-for-field mirrors; sizes as laid out by the C compiler
+    assert C.sizeof(capi.RtObjectDesc) == 4 * (4 + 3 + 3 + 3 + 2 + 3 + 12 + 2 + 1)
+    assert C.sizeof(capi.RtTextureDesc) == 32
+    assert C.sizeof(capi.RtCameraDesc) == 64
+    assert C.sizeof(capi.RtTiming) == 40
+    assert C.sizeof(capi.RtLaunchInfo) == 24
+
+
+def _create(desc):
+    lib = capi.load_library()
+    h = C.c_void_p()
+    rc = lib.rt_scene_create(C.byref(desc), 0, C.byref(h))
+    if h:
+        lib.rt_scene_destroy(h)
+    return rc, lib.rt_last_error().decode()
+
+
+def _copy_desc(src):
+    d = capi.RtSceneDesc()
+    C.memmove(C.byref(d), src, C.sizeof(d))
+    return d
+
+
+def test_invalid_descriptions_are_rejected_before_touching_a_device():
+    host = HostScene.builtin()
+    d = _copy_desc(host.desc)
+    d.n_objects = -1
+    assert _create(d)[0] == capi.RT_ERR_INVALID
+    d = _copy_desc(host.desc)
+    d.shadow_end = 33
+    rc, msg = _create(d)
+    assert rc == capi.RT_ERR_INVALID and "shadow" in msg
+    d = _copy_desc(host.desc)
+    objs = (capi.RtObjectDesc * 32)(*[d.objects[i] for i in range(32)])
+    objs[5].kind = 7
+    d.objects = objs
+    assert _create(d)[0] == capi.RT_ERR_INVALID
+    objs[5].kind = 0
+    objs[9].texture = 3
+    assert _create(d)[0] == capi.RT_ERR_INVALID
+    lib = capi.load_library()
+    assert lib.rt_scene_create(None, 0, None) == capi.RT_ERR_INVALID
+    assert lib.rt_render(None, None, 4, 4, 0, 4, 1, None) == capi.RT_ERR_INVALID
+    assert lib.rt_get_timing(None, None) == capi.RT_ERR_INVALID
+    assert lib.rt_scene_destroy(None) == capi.RT_OK
+
+
+def test_no_gpu_means_no_render(have_gpu):
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    from tilecoderaytracer_amd import Renderer
+    with pytest.raises(RtError) as e:
+        Renderer(HostScene.builtin())
+    assert e.value.code == capi.RT_ERR_NO_DEVICE
+    lib = capi.load_library()
+    host = HostScene.builtin()
+    import numpy as np
+    out = np.zeros((8, 8, 3), np.float32)
+    rc = lib.rt_render_multi(host.desc, host.camera, 8, 8, 1, 1, out.ctypes.data)
+    assert rc == capi.RT_ERR_NO_DEVICE and not out.any()
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under the package, include/
+    or bench.py's product path may import, link or load it."""
+    bad = []
+    pkg = os.path.join(ROOT, "tilecoderaytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"liboracle|rt_oracle|oracle_lib|orc_render", text):
+                    bad.append(os.path.join(dirpath, f))
+    # build.py may BUILD the oracle (building the checker is not using it) but not load it
+    bad = [b for b in bad if not b.endswith(os.path.join("tilecoderaytracer_amd", "build.py"))]
+    assert not bad, bad
+    for lib in ("libtcrt.so", "libtcrt_host.so"):
+        blob = open(os.path.join(pkg, "lib", lib), "rb").read()
+        assert b"orc_render" not in blob and b"liboracle" not in blob
