@@ -37,3 +37,209 @@ def test_scene_bit_exact(oracle, name, W, H, depth):
     ref = oracle.OracleScene.named(name).render(W, H, depth)
     r = Renderer(HostScene.named(name))
     assert_same(r.render(W, H, depth), ref, f"{name} {W}x{H} d{depth}")
+
+
+# ---------------------------------------------------------------- fixtures
+import hashlib
+import json
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("key", ["b64d4", "g32_64d4", "g16_64d8"])
+def test_golden_fixtures(oracle, key):
+    """Committed fixtures whose SHA-256 SURVEY.md App. D recorded from the reference."""
+    name, W, H, depth, digest = oracle.SURVEY_PINS[key]
+    want = np.fromfile(os.path.join(GOLDEN, key + ".f32"), dtype=np.float32).reshape(W, H, 3)
+    got = Renderer(HostScene.named(name)).render(W, H, depth)
+    assert_same(got, want, key)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == digest
+
+
+@pytest.mark.parametrize("key", ["b256d4", "g32d4", "g16d8", "b512d3"])
+def test_survey_digests_on_gpu(oracle, key):
+    name, W, H, depth, digest = oracle.SURVEY_PINS[key]
+    got = Renderer(HostScene.named(name)).render(W, H, depth)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == digest
+
+
+def test_extra_digests():
+    extra = json.load(open(os.path.join(GOLDEN, "extra.json")))
+    for key, digest in extra.items():
+        name, size, d = key.split("_")
+        W, H = (int(v) for v in size.split("x"))
+        got = Renderer(HostScene.named(name)).render(W, H, int(d[1:]))
+        assert hashlib.sha256(got.tobytes()).hexdigest() == digest, key
+
+
+# ------------------------------------------------------------- edge cases
+def test_shipped_configuration_depth_50(oracle):
+    """500 x 504, MAX_RECURSION_LEVEL 50 (src/rt_project_parameters.h:65-66,73)."""
+    ref = oracle.OracleScene.builtin().render(500, 504, 50)
+    assert_same(Renderer(HostScene.builtin()).render(500, 504, 50), ref, "shipped config")
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 3, 5, 8, 13])
+def test_depths(oracle, depth):
+    ref = oracle.OracleScene.grid(6, True).render(80, 72, depth)
+    assert_same(Renderer(HostScene.grid(6, True)).render(80, 72, depth), ref, f"depth {depth}")
+
+
+def test_two_mirrors_scene_3920_objects(oracle):
+    """The reference's own many-sphere scene: 3 920 objects, facing mirrors."""
+    ref = oracle.OracleScene.two_mirrors().render(40, 40, 6)
+    assert_same(Renderer(HostScene.two_mirrors()).render(40, 40, 6), ref, "two mirrors")
+
+
+def test_empty_scene_is_background():
+    r = Renderer(HostScene.empty())
+    img = r.render(33, 17, 4)
+    assert (img == np.float32(0.75)).all()
+
+
+def test_lights_only_and_single_pixel(oracle):
+    host, orc = HostScene.empty(), oracle.OracleScene()
+    for s in (host, orc):
+        i = s.add_sphere((0.0, 4.0, 0.0), 1.5)
+        s.set_light(i)
+        s.set_intensity(i, 0.5)
+    assert_same(Renderer(host).render(1, 1, 4), orc.render(1, 1, 4), "1x1")
+    assert_same(Renderer(host).render(31, 3, 4), orc.render(31, 3, 4), "31x3")
+
+
+def test_empty_strip_and_ragged_sizes(oracle):
+    r = Renderer(HostScene.builtin())
+    assert r.render(64, 64, 2, 10, 10).shape == (0, 64, 3)
+    orc = oracle.OracleScene.builtin()
+    for W, H in ((1, 130), (130, 1), (67, 19), (5, 257)):
+        assert_same(r.render(W, H, 3), orc.render(W, H, 3), f"{W}x{H}")
+
+
+def test_strips_are_bit_identical_to_the_full_render(oracle):
+    r = Renderer(HostScene.grid(8, True))
+    full = r.render(96, 64, 4)
+    assert_same(full, oracle.OracleScene.grid(8, True).render(96, 64, 4), "full")
+    for x0, x1 in ((0, 24), (24, 48), (48, 96), (95, 96), (13, 14), (1, 95)):
+        assert_same(r.render(96, 64, 4, x0, x1), full[x0:x1], f"strip {x0}:{x1}")
+
+
+@pytest.mark.parametrize("tile_z", [1, 2, 4, 8, 16, 32, 64])
+def test_tile_shapes_do_not_change_results(oracle, tile_z):
+    r = Renderer(HostScene.builtin())
+    r.set_option("tile_z", tile_z)
+    assert_same(r.render(150, 70, 4), oracle.OracleScene.builtin().render(150, 70, 4), f"tile_z {tile_z}")
+
+
+@pytest.mark.parametrize("block", [64, 128, 192, 256])
+def test_block_sizes_do_not_change_results(oracle, block):
+    r = Renderer(HostScene.grid(5, True))
+    r.set_option("block_threads", block)
+    assert_same(r.render(90, 50, 6), oracle.OracleScene.grid(5, True).render(90, 50, 6), f"block {block}")
+    assert r.launch_info().block_threads == block
+
+
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_random_scenes(oracle, seed):
+    """Mixed primitives in shuffled index order, textured finite planes, random
+    materials -- exercises run splitting, tie order and every shading branch."""
+    from scene_gen import build_random
+    host = build_random(HostScene.empty(), seed, shadows=(seed % 3 != 0))
+    orc = build_random(oracle.OracleScene(), seed, shadows=(seed % 3 != 0))
+    assert_same(Renderer(host).render(72, 56, 5), orc.render(72, 56, 5), f"seed {seed}")
+
+
+def test_partial_shadow_range(oracle):
+    """Scene::SetObjectIndices(rank, size) narrows the shadow scan (src/Scene.cpp:486-504)."""
+    from scene_gen import build_random
+    for rank, size in ((0, 2), (1, 2), (2, 3)):
+        host = build_random(HostScene.empty(), 5, shadows=False)
+        orc = build_random(oracle.OracleScene(), 5, shadows=False)
+        host.set_object_indices(rank, size)
+        orc.set_object_indices(rank, size)
+        assert_same(Renderer(host).render(64, 48, 4), orc.render(64, 48, 4), f"indices {rank}/{size}")
+
+
+def test_depth_too_deep_for_lds_is_an_error_not_a_fallback():
+    from tilecoderaytracer_amd import RtError, capi
+    r = Renderer(HostScene.builtin())
+    with pytest.raises(RtError) as e:
+        r.render(8, 8, 100000)
+    assert e.value.code == capi.RT_ERR_CAPACITY
+
+
+# ------------------------------------------- full-size (BASELINE.json sizes)
+def test_4096_builtin_depth4_properties(oracle):
+    """configs[1] at full size.  (a) (float)(64k)/4096 == (float)k/64, so the
+    stride-64 subsample must equal the committed 64x64 fixture; (b) columns at
+    odd offsets are compared with the oracle directly; (c) determinism."""
+    r = Renderer(HostScene.builtin())
+    img = r.render(4096, 4096, 4)
+    want = np.fromfile(os.path.join(GOLDEN, "b64d4.f32"), dtype=np.float32).reshape(64, 64, 3)
+    assert_same(np.ascontiguousarray(img[::64, ::64]), want, "stride-64 subsample")
+    orc = oracle.OracleScene.builtin()
+    for x0 in (1, 1001, 2047, 3333, 4095):
+        assert_same(img[x0:x0 + 1], orc.render(4096, 4096, 4, x0, x0 + 1), f"column {x0}")
+    assert hashlib.sha256(img.tobytes()).hexdigest() == hashlib.sha256(r.render(4096, 4096, 4).tobytes()).hexdigest()
+    assert np.isfinite(img).all() and img.max() > 1.0
+
+
+def test_4096_grid32_depth4_columns(oracle):
+    """configs[2] at full size: sampled columns against the oracle + the 64x64 subsample."""
+    r = Renderer(HostScene.grid(32, True))
+    img = r.render(4096, 4096, 4)
+    orc = oracle.OracleScene.grid(32, True)
+    assert_same(np.ascontiguousarray(img[::64, ::64]), orc.render(64, 64, 4), "stride-64 subsample")
+    for x0 in (777, 2049):
+        assert_same(img[x0:x0 + 1], orc.render(4096, 4096, 4, x0, x0 + 1), f"column {x0}")
+
+
+def test_4096_grid16_depth8_columns(oracle):
+    """configs[4] at full size."""
+    r = Renderer(HostScene.grid(16, True))
+    img = r.render(4096, 4096, 8)
+    orc = oracle.OracleScene.grid(16, True)
+    assert_same(np.ascontiguousarray(img[::64, ::64]), orc.render(64, 64, 8), "stride-64 subsample")
+    for x0 in (123, 3001):
+        assert_same(img[x0:x0 + 1], orc.render(4096, 4096, 8, x0, x0 + 1), f"column {x0}")
+
+
+def test_render_device_into_torch_memory(oracle):
+    """The device-pointer entry point used by bench.py and the multi-GPU path."""
+    import torch
+    host = HostScene.builtin()
+    r = Renderer(host)
+    buf = torch.zeros((40, 48, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    r.render_device(80, 48, 4, 20, 60, buf.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ref = oracle.OracleScene.builtin().render(80, 48, 4, 20, 60)
+    assert_same(buf.cpu().numpy(), ref, "render_device")
+    assert r.timing().launches >= 1
+
+
+def test_render_multi_single_gpu(oracle):
+    """rt_render_multi with ngpu = 1 (the only size a one-GPU box can run)."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    host = HostScene.builtin()
+    out = np.zeros((50, 30, 3), np.float32)
+    capi.check(capi.load_library().rt_render_multi(host.desc, host.camera, 50, 30, 3, 1, out.ctypes.data))
+    assert_same(out, oracle.OracleScene.builtin().render(50, 30, 3), "rt_render_multi")
+    rc = capi.load_library().rt_render_multi(host.desc, host.camera, 50, 30, 3, 64, out.ctypes.data)
+    assert rc == capi.RT_ERR_INVALID
+
+
+def test_host_executable_writes_the_reference_log(oracle, tmp_path):
+    """tcrt_raytracer = the reference's main(): default run writes raytracer_screen.txt."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "tilecoderaytracer_amd", "bin", "tcrt_raytracer")
+    out = tmp_path / "raytracer_screen.txt"
+    subprocess.run([exe, "--width", "64", "--height", "48", "--depth", "3", "--out", str(out)], check=True,
+                   stdout=subprocess.PIPE, cwd=tmp_path)
+    ref = oracle.OracleScene.builtin().render(64, 48, 3)
+    want = tmp_path / "want.txt"
+    oracle.write_screen_txt(str(want), ref, 0.0, 0.0)
+    got_lines = out.read_bytes().split(b"\n")
+    want_lines = want.read_bytes().split(b"\n")
+    assert got_lines[:7] == want_lines[:7] and got_lines[9:] == want_lines[9:]   # only the two timing lines vary
