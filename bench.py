@@ -65,12 +65,33 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the
+    cgroup CPU quota (a container can see 256 CPUs and be allowed 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(scene_name, W, H, depth, sample_columns):
     """Time the CPU oracle on all host cores over evenly spread column chunks."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib  # noqa: E402  (the oracle is the thing timed here, nothing else uses it)
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     chunk = 8
     n_chunks = max(cores, sample_columns // chunk)
     n_chunks = min(n_chunks, W // chunk)
@@ -230,7 +251,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cols = args.cpu_sample_columns or {"builtin": 1024, "builtin8k": 512}.get(args.workload, 64)
+                cols = args.cpu_sample_columns or {"builtin": 4096, "builtin8k": 2048}.get(args.workload, 64)
                 out["cpu_baseline"] = cpu_baseline(scene_name, W, H, depth, cols)
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = None

@@ -1,10 +1,25 @@
-import sys, time
-sys.path.insert(0, '.')
+"""Kernel-time sweep over the bench workloads (development aid)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tilecoderaytracer_amd import HostScene, Renderer
-for name, W, H, d in [("builtin", 4096, 4096, 4), ("grid32", 2048, 2048, 4), ("grid16", 2048, 2048, 8)]:
+import torch
+opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+cases = [("builtin", 4096, 4), ("grid32", 4096, 4), ("grid32-noshadow", 4096, 4), ("grid16", 4096, 8)]
+if "only" in opts:
+    cases = [c for c in cases if c[0] in opts["only"].split(",")]
+for name, S, d in cases:
     r = Renderer(HostScene.named(name))
-    r.render(256, 256, d)
+    for k in ("tile_z", "block_threads"):
+        if k in opts:
+            r.set_option(k, int(opts[k]))
+    buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    r.render_device(S, S, d, 0, S, buf.data_ptr(), st); torch.cuda.synchronize()
     r.reset_timing()
-    t = time.time(); a = r.render(W, H, d); wall = time.time() - t
+    n = 5 if name == "builtin" else 2
+    for _ in range(n):
+        r.render_device(S, S, d, 0, S, buf.data_ptr(), st)
+    torch.cuda.synchronize()
     tm = r.timing(); li = r.launch_info()
-    print(f"{name} {W}x{H} d{d}: kernel {tm.last_kernel_ms:.3f} ms = {W*H/tm.last_kernel_ms/1e3:.1f} Mrays/s; wall {wall:.3f}s; block {li.block_threads} lds {li.lds_bytes} grid {li.grid_blocks}; mean {a.mean():.6f}", flush=True)
+    ms = tm.sum_kernel_ms / tm.launches
+    print(f"{name:16s} {S}x{S} d{d}: {ms:9.3f} ms  {S*S/ms/1e3:9.1f} Mrays/s  block {li.block_threads} lds {li.lds_bytes} tile {li.tile_x}x{li.tile_z}", flush=True)

@@ -33,6 +33,12 @@ typedef float sdecimal32;                       /* src/rt_project_parameters.h:4
 
 #define CELIO_MAX_OBJECT_COUNT 4000             /* src/Scene.h:8 */
 
+/* The reference prints progress/diagnostic lines to stdout (e.g.
+ * "Changing Camera Scene.", src/Camera.cpp:44).  The executable turns them on
+ * to reproduce its console output; libraries keep them off so that a caller's
+ * stdout (bench.py's single JSON line) stays clean. */
+inline bool &verbose() { static bool v = false; return v; }
+
 /* src/vector3d.h:31-163 */
 class vector3d {
 public:
@@ -145,7 +151,7 @@ public:
     float getRefractiveFactor() const { return refractive_factor; }
 private:
     void warn(const char *which) const {        /* the reference's sanity print, :34,47,54 */
-        if ((absorption_factor + reflective_factor + refractive_factor) > 1)
+        if (verbose() && (absorption_factor + reflective_factor + refractive_factor) > 1)
             std::printf("***ERROR. Setting %s Factor.\n Ab: %f\n Refl: %f\n Refr: %f\n", which,
                         absorption_factor, reflective_factor, refractive_factor);
     }
@@ -299,7 +305,7 @@ public:
         derive();
     }
     void setSceneTwoMirrors() {                 /* :42-69 */
-        std::printf("Changing Camera Scene.\n");
+        if (verbose()) std::printf("Changing Camera Scene.\n");
         screen_origin = vector3d(0, 0, 2.5);
         vector_outwards = vector3d(.00, 1, -.00);
         vector_horizontal = vector3d(1, -.00, 0);
@@ -358,7 +364,7 @@ public:
     int getObjectCount() const { return object_count; }
     void addObject(SceneObject *new_obj_ptr) {          /* src/Scene.cpp:470-479: max 3999 */
         if (object_count + 1 >= CELIO_MAX_OBJECT_COUNT) {
-            std::printf("***ERROR. Added too many objects to scene.\n");
+            if (verbose()) std::printf("***ERROR. Added too many objects to scene.\n");
         } else {
             objects.push_back(new_obj_ptr);
             ++object_count;
@@ -583,7 +589,7 @@ inline int Scene::initializeTwoMirrors(Camera *myCamera) {
             }
         }
     }
-    std::printf("ObjectCount: %d\n", object_count);
+    if (verbose()) std::printf("ObjectCount: %d\n", object_count);
     myCamera->setSceneTwoMirrors();
     scene_object_start_index = 0;
     scene_object_final_index = object_count;

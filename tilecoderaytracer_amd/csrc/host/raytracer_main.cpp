@@ -57,6 +57,7 @@ int main(int argc, char **argv) {
         else return usage(argv[0]);
     }
     if (W <= 0 || H <= 0 || depth < 0 || gpus <= 0) return usage(argv[0]);
+    verbose() = true;                          /* console output like the reference's */
 
     if (gpus == 1) std::cout << "Single-Core RayTracing!" << std::endl << std::endl;
     else std::printf("\nMulti-Core RayTracing!\n\n");

@@ -55,60 +55,88 @@ __device__ __forceinline__ V3 normalize3(const V3 v) {
     return mk(v.x / length, v.y / length, v.z / length);
 }
 
+/* Wave-level "does any active lane need this": a uniform (scalar) branch, so
+ * the guarded block costs no exec-mask bookkeeping; lanes that do not need it
+ * run it anyway and discard the result. */
+__device__ __forceinline__ bool wave_any(const bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
 /* SceneSphere::collision reduced to its distance, src/SceneSphere.cpp:50-116.
- * Returns true when the reference would return a CollisionObject; *dist is
+ * *hit is true when the reference would return a CollisionObject; *dist is
  * then the distance it reports (v - sqrt(d^2), negative for inside hits). */
-__device__ __forceinline__ bool sphere_distance(const float4 s, const V3 o, const V3 d, float *dist) {
+__device__ __forceinline__ void sphere_distance(const float4 s, const V3 o, const V3 d, bool *hit, float *dist) {
     const V3 OE = mk(s.x - o.x, s.y - o.y, s.z - o.z);
     const float v = dot3(OE, d);
-    if (v < (float)0) return false;
     const float d_squared = s.w - (dot3(OE, OE) - v * v);
-    if (d_squared < (float)1E-9) return false;
-    const float sq = sqrtf(d_squared);
-    const float root1 = v - sq;
-    const float root2 = v + sq;
-    if (root2 > (float)0) {
-        if (root1 < (float)0) {
-            if (!(root2 < 65535.0f)) return false;
-        } else {
-            if (!(root1 < 65535.0f)) return false;
-        }
-    } else {
-        return false;
+    /* `if (v < 0) return NULL; ... if (d_squared < 1E-9) return NULL;` */
+    const bool candidate = !(v < (float)0) && !(d_squared < (float)1E-9);
+    *hit = false;
+    *dist = 0.0f;
+    if (wave_any(candidate)) {
+        const float sq = sqrtf(d_squared);
+        const float root1 = v - sq;
+        const float root2 = v + sq;
+        /* the root2 > 0 / root1 < 0 / "< 65535" ladder of :93-116 */
+        const bool ok = (root2 > (float)0) && ((root1 < (float)0) ? (root2 < 65535.0f) : (root1 < 65535.0f));
+        *hit = candidate && ok;
+        *dist = root1;
     }
-    *dist = root1;
-    return true;
+}
+
+/* Plane prefilter shared by both plane kinds.  t = numerator / denom is only
+ * worth computing when it can matter; both skips are exact:
+ *  (1) unless numerator and denom are non-zero with equal signs, t <= 0 (or
+ *      NaN, which loses every later comparison): the reference's `t < 1E-10` /
+ *      `t < 1E-5` rejects it;
+ *  (2) if |numerator| > |denom| * bound (with a 1e-6 margin for the rounding of
+ *      the product, and only when the product is a normal number), the true
+ *      quotient exceeds `bound`, so the correctly rounded t is >= bound and the
+ *      caller's `t < bound` (nearest so far / distance to the light) is false. */
+__device__ __forceinline__ bool plane_candidate(const float numerator, const float denom, const float bound) {
+    const bool same_sign = (numerator > 0.0f && denom > 0.0f) || (numerator < 0.0f && denom < 0.0f);
+    const float prod = fabsf(denom) * bound;
+    const bool too_far = (prod >= 1.0e-30f) && (fabsf(numerator) > prod * 1.000001f);
+    return same_sign && !too_far;
 }
 
 /* SceneInfinitePlane::collision reduced to t, src/SceneInfinitePlane.cpp:29-51 */
-__device__ __forceinline__ bool infinite_plane_distance(const float4 q0, const V3 o, const V3 d, float *dist) {
+__device__ __forceinline__ void infinite_plane_distance(const float4 q0, const V3 o, const V3 d, const float bound,
+                                                        bool *hit, float *dist) {
     const V3 n = xyz(q0);
     const float numerator = -q0.w - dot3(o, n);
     const float denom = dot3(d, n);
-    if (denom == (float)0) return false;
-    const float t = numerator / denom;
-    if (t < (float)1E-10) return false;
-    *dist = t;
-    return true;
+    const bool candidate = plane_candidate(numerator, denom, bound);
+    *hit = false;
+    *dist = 0.0f;
+    if (wave_any(candidate)) {
+        const float t = numerator / denom;
+        *hit = candidate && !(t < (float)1E-10);
+        *dist = t;
+    }
 }
 
 /* SceneFinitePlane::collision reduced to t, src/SceneFinitePlane.cpp:86-124 */
-__device__ __forceinline__ bool finite_plane_distance(const float4 *g, const V3 o, const V3 d, float *dist) {
+__device__ __forceinline__ void finite_plane_distance(const float4 *g, const V3 o, const V3 d, const float bound,
+                                                      bool *hit, float *dist) {
     const float4 q0 = g[0];
     const V3 n = xyz(q0);
     const float numerator = -q0.w - dot3(o, n);
     const float denom = dot3(d, n);
-    if (denom == 0) return false;
-    const float t = numerator / denom;
-    if ((double)t < 1E-5) return false;          /* the reference compares in double, :102 */
-    const float4 q1 = g[1], q2 = g[2], q3 = g[3];
-    const V3 p = add3(scale3(d, t), o);
-    const V3 PO = sub3(p, xyz(q1));
-    const float x = dot3(PO, xyz(q2));
-    const float y = dot3(PO, xyz(q3));
-    if (x < 0 || x > q1.w || y < 0 || y > q2.w) return false;
-    *dist = t;
-    return true;
+    const bool candidate = plane_candidate(numerator, denom, bound);
+    *hit = false;
+    *dist = 0.0f;
+    if (wave_any(candidate)) {
+        const float4 q1 = g[1], q2 = g[2], q3 = g[3];
+        const float t = numerator / denom;
+        const V3 p = add3(scale3(d, t), o);
+        const V3 PO = sub3(p, xyz(q1));
+        const float x = dot3(PO, xyz(q2));
+        const float y = dot3(PO, xyz(q3));
+        /* `t < 1E-5` is a double comparison in the reference (:102);
+         * (double)t < 1e-5  <=>  t <= 9.99999974737875e-06f, the float just below 1e-5 */
+        const bool miss = (t <= 9.99999974737875e-06f) || (x < 0) || (x > q1.w) || (y < 0) || (y > q2.w);
+        *hit = candidate && !miss;
+        *dist = t;
+    }
 }
 
 /* getCollision, src/RayTracer.cpp:50-89: first strictly-smaller distance in
@@ -122,23 +150,24 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
         const RtRun run = runs[r];
         const float4 *g = lds + run.geom_off;
         if (run.kind == RT_KIND_SPHERE) {
+#pragma unroll 2
             for (int i = 0; i < run.count; ++i) {
-                float t;
-                if (sphere_distance(g[i], o, d, &t) && t < best) { best = t; best_idx = run.first + i; }
+                bool hit; float t;
+                sphere_distance(g[i], o, d, &hit, &t);
+                if (hit && t < best) { best = t; best_idx = run.first + i; }
             }
         } else if (run.kind == RT_KIND_INFINITE_PLANE) {
             for (int i = 0; i < run.count; ++i) {
-                float t;
-                if (infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, &t) && t < best) {
-                    best = t; best_idx = run.first + i;
-                }
+                bool hit; float t;
+                infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, best, &hit, &t);
+                if (hit && t < best) { best = t; best_idx = run.first + i; }
             }
         } else {
+#pragma unroll 2
             for (int i = 0; i < run.count; ++i) {
-                float t;
-                if (finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, &t) && t < best) {
-                    best = t; best_idx = run.first + i;
-                }
+                bool hit; float t;
+                finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, best, &hit, &t);
+                if (hit && t < best) { best = t; best_idx = run.first + i; }
             }
         }
     }
@@ -148,27 +177,41 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
 
 /* inShadeCollisionDetection, src/RayTracer.cpp:709-739: any non-light object
  * of the scan range with distance < dist_to_light blocks.  A boolean OR, so
- * the scan order is free; lanes drop out as soon as they are blocked. */
+ * the scan order is free; the wave stops when every lane is blocked. */
 __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restrict__ shadow_runs,
                                          const float4 *lds, const V3 o, const V3 d, const float dist_to_light) {
     bool blocked = false;
-    for (int r = 0; r < p.n_shadow_runs && !blocked; ++r) {
+    for (int r = 0; r < p.n_shadow_runs; ++r) {
+        if (!wave_any(!blocked)) break;
         const RtRun run = shadow_runs[r];
         const float4 *g = lds + run.geom_off;
         if (run.kind == RT_KIND_SPHERE) {
-            for (int i = 0; i < run.count && !blocked; ++i) {
-                float t;
-                if (sphere_distance(g[i], o, d, &t) && t < dist_to_light) blocked = true;
+            for (int i = 0; i < run.count; i += 2) {
+                if (!wave_any(!blocked)) break;
+                bool hit; float t;
+                sphere_distance(g[i], o, d, &hit, &t);
+                blocked = blocked || (hit && t < dist_to_light);
+                if (i + 1 < run.count) {
+                    sphere_distance(g[i + 1], o, d, &hit, &t);
+                    blocked = blocked || (hit && t < dist_to_light);
+                }
             }
         } else if (run.kind == RT_KIND_INFINITE_PLANE) {
-            for (int i = 0; i < run.count && !blocked; ++i) {
-                float t;
-                if (infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, &t) && t < dist_to_light) blocked = true;
+            for (int i = 0; i < run.count; ++i) {
+                bool hit; float t;
+                infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, dist_to_light, &hit, &t);
+                blocked = blocked || (hit && t < dist_to_light);
             }
         } else {
-            for (int i = 0; i < run.count && !blocked; ++i) {
-                float t;
-                if (finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, &t) && t < dist_to_light) blocked = true;
+            for (int i = 0; i < run.count; i += 2) {
+                if (!wave_any(!blocked)) break;
+                bool hit; float t;
+                finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
+                blocked = blocked || (hit && t < dist_to_light);
+                if (i + 1 < run.count) {
+                    finite_plane_distance(g + (i + 1) * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
+                    blocked = blocked || (hit && t < dist_to_light);
+                }
             }
         }
     }
