@@ -60,7 +60,7 @@ struct rt_scene {
     void *d_fb = nullptr;
     size_t d_fb_bytes = 0;
     /* options */
-    int tile_z_log2 = 4;          /* 4 columns x 16 rows per wavefront */
+    int tile_z_log2 = 2;          /* 16 columns x 4 rows per wavefront (measured best on MI355X: wide tiles diverge least) */
     int block_threads_opt = 0;    /* 0 = auto */
     /* timing */
     EventPair ev[kEventRing];
