@@ -9,7 +9,9 @@ torch.distributed.run) the image is split into N contiguous x-strips
 (the framebuffer is x-major, pixels[x][z], so a strip is one contiguous
 block), every rank renders its strip into HBM and the strips are gathered to
 rank 0 with RCCL (torch.distributed backend "nccl") -- STRONG scaling: the
-image is fixed, the work per GPU shrinks.
+image is fixed, the work per GPU shrinks.  Frames are independent, so the
+gather of frame k (RCCL's stream) overlaps the render of frame k+1 (two strip
+buffers; --no-overlap serialises them).
 
 Timed region: barrier + synchronize, K steps (kernel + gather), barrier +
 synchronize; MAX over ranks.  The framebuffer stays in HBM (inputs -- the
@@ -62,6 +64,8 @@ def parse_args():
                     help="columns of the image the CPU oracle renders (default: sized for ~10-30 CPU-seconds)")
     ap.add_argument("--tile-z", type=int, default=0, help="wavefront tile height override (speed only)")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: gather each frame before rendering the next (no render/gather pipelining)")
     return ap.parse_args()
 
 
@@ -145,7 +149,7 @@ def main():
     import torch
     import torch.distributed as dist
     from tilecoderaytracer_amd import HostScene, Renderer
-    from tilecoderaytracer_amd.distributed import alloc_full, gather_strips, strip_bounds
+    from tilecoderaytracer_amd.distributed import StripPipeline
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
@@ -165,19 +169,14 @@ def main():
     if args.block_threads:
         renderer.set_option("block_threads", args.block_threads)
 
-    x0, x1, strip = strip_bounds(W, world, rank)
-    strip_buf = torch.empty((strip, H, 3), dtype=torch.float32, device=dev)
-    gather_list = None
-    if world > 1 and rank == 0:
-        _full, gather_list = alloc_full(W, H, world, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():
-        renderer.render_device(W, H, depth, x0, x1, strip_buf.data_ptr(), stream)
-        if world > 1:
-            gather_strips(strip_buf, gather_list, dst=0)
+    pipe = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap)
+    x0, x1, strip = pipe.x0, pipe.x1, pipe.strip
+    pipe.render = lambda buf: renderer.render_device(W, H, depth, x0, x1, buf.data_ptr(), stream)
+    step = pipe.step
 
     def fence():
+        pipe.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -228,7 +227,9 @@ def main():
                 "workload": f"{scene_name} scene, {W}x{H}, max depth {depth}",
                 "baseline_config": cfg_note,
                 "objects": host.object_count,
-                "partition": f"{world} x-strip(s) of {strip} columns" + (", RCCL gather to rank 0" if world > 1 else ""),
+                "partition": f"{world} x-strip(s) of {strip} columns" + (
+                    ", RCCL gather to rank 0" + ("" if args.no_overlap else ", gather of frame k overlapped with render of frame k+1")
+                    if world > 1 else ""),
                 "block_threads": li.block_threads,
                 "lds_bytes_per_block": li.lds_bytes,
                 "wave_tile": f"{li.tile_x}x{li.tile_z}",

@@ -17,6 +17,44 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+def _pipeline_worker(rank, world, W, H, depth, init_file, out_file, overlap):
+    """bench.py's loop: StripPipeline.step() K times, frames differ so stale data would show."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle_lib
+    from tilecoderaytracer_amd.distributed import StripPipeline
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    scene = oracle_lib.OracleScene.builtin()
+    frame = {"d": 0}
+
+    def render(buf):
+        x0, x1 = pipe.x0, pipe.x1
+        buf.zero_()
+        if x1 > x0:                              # frame k is rendered at depth k % 3 (stands in for the kernel)
+            buf[: x1 - x0] = torch.from_numpy(scene.render(W, H, frame["d"] % 3, x0, x1))
+        frame["d"] += 1
+
+    pipe = StripPipeline(W, H, world, rank, "cpu", render, overlap=overlap)
+    for _ in range(5):
+        pipe.step()
+    img = pipe.image(W)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_file, img.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_pipelined_gather_delivers_the_last_frame(oracle, overlap):
+    world, W, H = 2, 30, 16
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.npy")
+        mp.spawn(_pipeline_worker, args=(world, W, H, 0, init_file, out_file, overlap), nprocs=world, join=True)
+        got = np.load(out_file)
+    ref = oracle.OracleScene.builtin().render(W, H, 4 % 3)      # the 5th frame
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def _worker(rank, world, W, H, depth, init_file, out_file):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)

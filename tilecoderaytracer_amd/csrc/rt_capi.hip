@@ -7,6 +7,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -50,7 +51,12 @@ constexpr int kEventRing = 64;
 
 struct rt_scene {
     int device = 0;
-    /* host copies */
+    /* the caller's description, copied */
+    std::vector<rt_object_desc> objects;
+    std::vector<rt_texture_desc> textures;
+    int shadow_begin = 0, shadow_end = 0;
+    float null_color[3] = {0.75f, 0.75f, 0.75f};
+    /* packed tables (host copies) */
     std::vector<Quad> image;
     std::vector<RtRun> runs, shadow_runs;
     RtParams base{};              /* table offsets filled at create */
@@ -62,6 +68,8 @@ struct rt_scene {
     /* options */
     int tile_z_log2 = 2;          /* 16 columns x 4 rows per wavefront (measured best on MI355X: wide tiles diverge least) */
     int block_threads_opt = 0;    /* 0 = auto */
+    int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
+    int n_clusters = 0;
     /* timing */
     EventPair ev[kEventRing];
     int ev_next = 0;
@@ -73,30 +81,119 @@ struct rt_scene {
 
 namespace {
 
-bool finite3(const float *v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+/* ---- sphere clusters (rt_tables.h "clustered sphere runs") ----------------
+ * A long run of spheres is regrouped into spatial leaves of <= leaf spheres
+ * (k-d median split of the centres).  Each leaf gets a bounding ball that
+ * contains every member sphere; the kernel skips a leaf only when a
+ * conservative test proves no member can be a candidate hit, so results are
+ * unchanged (rt_kernel.hip, cluster_needed()). */
+struct Leaf { std::vector<int> members; float c[3]; float rm; };
 
-/* Build the LDS image + run lists from the description. */
-int pack_scene(const rt_scene_desc *desc, rt_scene *s) {
-    const int n = desc->n_objects;
-    if (n < 0) return fail(RT_ERR_INVALID, "n_objects < 0");
-    if (n > 0 && !desc->objects) return fail(RT_ERR_INVALID, "objects is NULL");
-    if (desc->n_textures < 0 || (desc->n_textures > 0 && !desc->textures))
-        return fail(RT_ERR_INVALID, "bad textures");
-    if (desc->shadow_begin < 0 || desc->shadow_end < desc->shadow_begin || desc->shadow_end > n)
-        return fail(RT_ERR_INVALID, "shadow range must satisfy 0 <= begin <= end <= n_objects");
-    (void)finite3;
+void make_leaf(const rt_object_desc *objs, const std::vector<int> &ids, std::vector<Leaf> &out) {
+    Leaf L;
+    L.members = ids;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i : ids)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], (double)objs[i].origin[k]);
+            hi[k] = std::max(hi[k], (double)objs[i].origin[k]);
+        }
+    for (int k = 0; k < 3; ++k) L.c[k] = (float)(0.5 * (lo[k] + hi[k]));
+    /* radius measured from the float-rounded centre the kernel will use */
+    double R = 0.0;
+    for (int i : ids) {
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double d = (double)objs[i].origin[k] - (double)L.c[k];
+            d2 += d * d;
+        }
+        R = std::max(R, std::sqrt(d2) + std::fabs((double)objs[i].radius));
+    }
+    /* inflate: 1 % + an absolute term, then round up to float */
+    L.rm = std::nextafter((float)(R * 1.01 + 1e-4), INFINITY);
+    out.push_back(std::move(L));
+}
 
-    std::vector<Quad> geom, lights, mats, texs;
-    std::vector<uint32_t> objinfo((size_t)n, 0u);
-    std::vector<int> geom_off((size_t)n, 0);
+void split_leaves(const rt_object_desc *objs, std::vector<int> ids, int leaf, std::vector<Leaf> &out) {
+    if ((int)ids.size() <= leaf) { make_leaf(objs, ids, out); return; }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i : ids)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], (double)objs[i].origin[k]);
+            hi[k] = std::max(hi[k], (double)objs[i].origin[k]);
+        }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k) if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+    /* split so that the left part is a whole number of leaves */
+    const size_t n_leaves = (ids.size() + (size_t)leaf - 1) / (size_t)leaf;
+    const size_t mid = (n_leaves / 2) * (size_t)leaf;
+    std::nth_element(ids.begin(), ids.begin() + (long)mid, ids.end(), [&](int a, int b) {
+        if (objs[a].origin[axis] != objs[b].origin[axis]) return objs[a].origin[axis] < objs[b].origin[axis];
+        return a < b;
+    });
+    split_leaves(objs, std::vector<int>(ids.begin(), ids.begin() + (long)mid), leaf, out);
+    split_leaves(objs, std::vector<int>(ids.begin() + (long)mid, ids.end()), leaf, out);
+}
+
+bool all_finite(const rt_object_desc &o) {
+    return std::isfinite(o.origin[0]) && std::isfinite(o.origin[1]) && std::isfinite(o.origin[2]) &&
+           std::isfinite(o.radius);
+}
+
+/* Build the LDS image + run lists from the stored description. */
+int pack_scene(rt_scene *s) {
+    const int n = (int)s->objects.size();
+    const rt_object_desc *objs = s->objects.data();
+    const int sb = s->shadow_begin, se = s->shadow_end;
+
+    std::vector<Quad> geom, lights, mats, texs, clusters;
+    std::vector<uint32_t> objinfo((size_t)n, 0u), cidx;
+    std::vector<int> geom_off((size_t)n, 0), mat_of((size_t)n, 0);
     std::map<std::vector<uint32_t>, int> mat_index;
 
+    /* materials (de-duplicated bit-wise), lights */
     for (int i = 0; i < n; ++i) {
-        const rt_object_desc &o = desc->objects[i];
-        if (o.kind != RT_KIND_SPHERE && o.kind != RT_KIND_INFINITE_PLANE && o.kind != RT_KIND_FINITE_PLANE)
-            return fail(RT_ERR_INVALID, "object " + std::to_string(i) + ": unknown kind");
-        if (o.texture < -1 || o.texture >= desc->n_textures)
-            return fail(RT_ERR_INVALID, "object " + std::to_string(i) + ": texture index out of range");
+        const rt_object_desc &o = objs[i];
+        const uint32_t mbits = (o.is_light ? 1u : 0u) | ((uint32_t)(o.texture + 1) << 1);
+        Quad m0 = {{o.color[0], o.color[1], o.color[2], o.diffuse}};
+        Quad m1 = {{o.specular, o.reflective, o.intensity, bits_to_float(mbits)}};
+        std::vector<uint32_t> key(8);
+        std::memcpy(key.data(), m0.v, 16);
+        std::memcpy(key.data() + 4, m1.v, 16);
+        auto it = mat_index.find(key);
+        if (it == mat_index.end()) {
+            const int mi = (int)mat_index.size();
+            if (mi > RT_MAX_MATERIALS) return fail(RT_ERR_CAPACITY, "too many distinct materials");
+            mat_index.emplace(key, mi);
+            mats.push_back(m0);
+            mats.push_back(m1);
+            mat_of[(size_t)i] = mi;
+        } else {
+            mat_of[(size_t)i] = it->second;
+        }
+        if (o.is_light) {
+            lights.push_back({{o.origin[0], o.origin[1], o.origin[2], o.intensity}});
+            lights.push_back({{o.color[0], o.color[1], o.color[2], bits_to_float((uint32_t)i)}});
+        }
+    }
+    for (const rt_texture_desc &x : s->textures) {
+        texs.push_back({{x.light[0], x.light[1], x.light[2], x.width}});
+        texs.push_back({{x.dark[0], x.dark[1], x.dark[2], x.height}});
+    }
+
+    /* runs of consecutive objects of one kind and one light flag, in index order */
+    struct Span { int kind, first, count; bool light; };
+    std::vector<Span> spans;
+    for (int i = 0; i < n; ++i) {
+        const bool light = objs[i].is_light != 0;
+        if (!spans.empty() && spans.back().kind == objs[i].kind && spans.back().light == light)
+            ++spans.back().count;
+        else
+            spans.push_back(Span{objs[i].kind, i, 1, light});
+    }
+
+    auto emit_geometry = [&](int i) {
+        const rt_object_desc &o = objs[i];
         geom_off[(size_t)i] = (int)geom.size();
         if (o.kind == RT_KIND_SPHERE) {
             geom.push_back({{o.origin[0], o.origin[1], o.origin[2], o.radius_squared}});
@@ -108,64 +205,82 @@ int pack_scene(const rt_scene_desc *desc, rt_scene *s) {
             geom.push_back({{o.vertical[0], o.vertical[1], o.vertical[2], 0.0f}});
             geom.push_back({{o.reverse_normal[0], o.reverse_normal[1], o.reverse_normal[2], 0.0f}});
         }
-        if (geom.size() > RT_MAX_GEOM_QUADS) return fail(RT_ERR_CAPACITY, "geometry table too large");
-
-        /* material row, de-duplicated bit-wise */
-        const uint32_t mbits = (o.is_light ? 1u : 0u) | ((uint32_t)(o.texture + 1) << 1);
-        Quad m0 = {{o.color[0], o.color[1], o.color[2], o.diffuse}};
-        Quad m1 = {{o.specular, o.reflective, o.intensity, bits_to_float(mbits)}};
-        std::vector<uint32_t> key(8);
-        std::memcpy(key.data(), m0.v, 16);
-        std::memcpy(key.data() + 4, m1.v, 16);
-        auto it = mat_index.find(key);
-        int mi;
-        if (it == mat_index.end()) {
-            mi = (int)mat_index.size();
-            if (mi > RT_MAX_MATERIALS) return fail(RT_ERR_CAPACITY, "too many distinct materials");
-            mat_index.emplace(key, mi);
-            mats.push_back(m0);
-            mats.push_back(m1);
-        } else {
-            mi = it->second;
-        }
-        objinfo[(size_t)i] = (uint32_t)geom_off[(size_t)i] | ((uint32_t)o.kind << 16) | ((uint32_t)mi << 20);
-
-        if (o.is_light) {
-            lights.push_back({{o.origin[0], o.origin[1], o.origin[2], o.intensity}});
-            lights.push_back({{o.color[0], o.color[1], o.color[2], bits_to_float((uint32_t)i)}});
-        }
-    }
-    for (int t = 0; t < desc->n_textures; ++t) {
-        const rt_texture_desc &x = desc->textures[t];
-        texs.push_back({{x.light[0], x.light[1], x.light[2], x.width}});
-        texs.push_back({{x.dark[0], x.dark[1], x.dark[2], x.height}});
-    }
-
-    /* runs: consecutive objects of one kind and one light flag, in index order */
-    auto build_runs = [&](int begin, int end, bool skip_lights, std::vector<RtRun> &out) {
-        out.clear();
-        for (int i = begin; i < end; ++i) {
-            const rt_object_desc &o = desc->objects[i];
-            if (skip_lights && o.is_light) continue;
-            if (!out.empty()) {
-                RtRun &b = out.back();
-                const rt_object_desc &prev = desc->objects[b.first + b.count - 1];
-                if (b.kind == o.kind && b.first + b.count == i && (prev.is_light != 0) == (o.is_light != 0)) {
-                    ++b.count;
-                    continue;
-                }
-            }
-            out.push_back(RtRun{o.kind, 1, i, geom_off[(size_t)i]});
-        }
     };
-    build_runs(0, n, false, s->runs);
-    build_runs(desc->shadow_begin, desc->shadow_end, true, s->shadow_runs);
+
+    s->runs.clear();
+    s->shadow_runs.clear();
+    s->n_clusters = 0;
+    /* Cluster/idx offsets are patched once the section bases are known. */
+    struct Pending { size_t run_pos; bool shadow; int cluster_first, cidx_first; };
+    std::vector<Pending> pending;
+
+    for (const Span &sp : spans) {
+        const int first = sp.first, last = sp.first + sp.count;             /* [first, last) */
+        /* part of the span inside the shadow scan range (lights never cast shadows) */
+        const int s0 = std::max(first, sb), s1 = std::min(last, se);
+        const bool in_shadow_all = !sp.light && s0 == first && s1 == last;
+        const bool in_shadow_none = sp.light || s0 >= s1;
+        bool cluster = sp.kind == RT_KIND_SPHERE && s->cluster_leaf > 0 && sp.count >= 4 * s->cluster_leaf &&
+                       (in_shadow_all || in_shadow_none);
+        if (cluster)
+            for (int i = first; i < last; ++i) cluster = cluster && all_finite(objs[i]);
+        if (cluster) {
+            std::vector<int> ids((size_t)sp.count);
+            for (int i = 0; i < sp.count; ++i) ids[(size_t)i] = first + i;
+            std::vector<Leaf> leaves;
+            split_leaves(objs, ids, s->cluster_leaf, leaves);
+            const int cluster_first = (int)(clusters.size() / RT_CLUSTER_QUADS);
+            const int cidx_first = (int)cidx.size();
+            for (const Leaf &L : leaves) {
+                const int member_off = (int)geom.size();
+                const int slot = (int)cidx.size() - cidx_first;
+                for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); }
+                clusters.push_back({{L.c[0], L.c[1], L.c[2], L.rm}});
+                clusters.push_back({{bits_to_float((uint32_t)member_off), bits_to_float((uint32_t)L.members.size()),
+                                     bits_to_float((uint32_t)slot), 0.0f}});
+            }
+            s->n_clusters += (int)leaves.size();
+            pending.push_back(Pending{s->runs.size(), false, cluster_first, cidx_first});
+            s->runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, (int)leaves.size(), 0, 0});
+            if (in_shadow_all) {
+                pending.push_back(Pending{s->shadow_runs.size(), true, cluster_first, cidx_first});
+                s->shadow_runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, (int)leaves.size(), 0, 0});
+            }
+        } else {
+            for (int i = first; i < last; ++i) emit_geometry(i);
+            s->runs.push_back(RtRun{sp.kind, sp.count, first, geom_off[(size_t)first]});
+            if (!sp.light && s0 < s1) s->shadow_runs.push_back(RtRun{sp.kind, s1 - s0, s0, geom_off[(size_t)s0]});
+        }
+        if (geom.size() > RT_MAX_GEOM_QUADS) return fail(RT_ERR_CAPACITY, "geometry table too large");
+    }
+    /* merge adjacent plain runs of the same kind (a light flag change does not matter for the nearest scan) */
+    {
+        std::vector<RtRun> merged;
+        std::vector<size_t> remap(s->runs.size());
+        for (size_t r = 0; r < s->runs.size(); ++r) {
+            const RtRun &cur = s->runs[r];
+            if (!merged.empty() && cur.kind != RT_KIND_SPHERE_CLUSTERED && merged.back().kind == cur.kind &&
+                merged.back().first + merged.back().count == cur.first) {
+                merged.back().count += cur.count;
+            } else {
+                merged.push_back(cur);
+            }
+            remap[r] = merged.size() - 1;
+        }
+        for (Pending &pd : pending) if (!pd.shadow) pd.run_pos = remap[pd.run_pos];
+        s->runs.swap(merged);
+    }
+    for (int i = 0; i < n; ++i)
+        objinfo[(size_t)i] = (uint32_t)geom_off[(size_t)i] | ((uint32_t)objs[i].kind << 16) |
+                             ((uint32_t)mat_of[(size_t)i] << 20);
 
     /* assemble the image */
     RtParams &b = s->base;
     std::memset(&b, 0, sizeof(b));
     s->image.clear();
     s->image.insert(s->image.end(), geom.begin(), geom.end());
+    const int clusters_off = (int)s->image.size();
+    s->image.insert(s->image.end(), clusters.begin(), clusters.end());
     b.lights_off = (int)s->image.size();
     s->image.insert(s->image.end(), lights.begin(), lights.end());
     b.mat_off = (int)s->image.size();
@@ -173,17 +288,78 @@ int pack_scene(const rt_scene_desc *desc, rt_scene *s) {
     b.tex_off = (int)s->image.size();
     s->image.insert(s->image.end(), texs.begin(), texs.end());
     b.objinfo_off = (int)s->image.size();
-    const size_t info_quads = ((size_t)n + 3) / 4;
-    s->image.resize(s->image.size() + info_quads, Quad{{0, 0, 0, 0}});
+    s->image.resize(s->image.size() + ((size_t)n + 3) / 4, Quad{{0, 0, 0, 0}});
     if (n > 0) std::memcpy(s->image[(size_t)b.objinfo_off].v, objinfo.data(), (size_t)n * 4);
+    const int cidx_off = (int)s->image.size();
+    s->image.resize(s->image.size() + (cidx.size() + 3) / 4, Quad{{0, 0, 0, 0}});
+    if (!cidx.empty()) std::memcpy(s->image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
+    for (const Pending &pd : pending) {
+        RtRun &run = pd.shadow ? s->shadow_runs[pd.run_pos] : s->runs[pd.run_pos];
+        run.geom_off = clusters_off + pd.cluster_first * RT_CLUSTER_QUADS;
+        run.first = cidx_off * 4 + pd.cidx_first;          /* u32 index of the run's member-index table */
+    }
     if (s->image.empty()) s->image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
     b.image_quads = (int)s->image.size();
     b.n_runs = (int)s->runs.size();
     b.n_shadow_runs = (int)s->shadow_runs.size();
     b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
-    for (int c = 0; c < 3; ++c) b.null_color[c] = desc->null_color[c];
+    for (int c = 0; c < 3; ++c) b.null_color[c] = s->null_color[c];
     if ((size_t)b.image_quads * 16 + 64 * RT_STACK_ENTRY_BYTES > RT_MAX_LDS_BYTES)
         return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
+    return RT_OK;
+}
+
+/* validate + copy the caller's description into the handle */
+int adopt_desc(const rt_scene_desc *desc, rt_scene *s) {
+    const int n = desc->n_objects;
+    if (n < 0) return fail(RT_ERR_INVALID, "n_objects < 0");
+    if (n > 0 && !desc->objects) return fail(RT_ERR_INVALID, "objects is NULL");
+    if (desc->n_textures < 0 || (desc->n_textures > 0 && !desc->textures))
+        return fail(RT_ERR_INVALID, "bad textures");
+    if (desc->shadow_begin < 0 || desc->shadow_end < desc->shadow_begin || desc->shadow_end > n)
+        return fail(RT_ERR_INVALID, "shadow range must satisfy 0 <= begin <= end <= n_objects");
+    for (int i = 0; i < n; ++i) {
+        const rt_object_desc &o = desc->objects[i];
+        if (o.kind != RT_KIND_SPHERE && o.kind != RT_KIND_INFINITE_PLANE && o.kind != RT_KIND_FINITE_PLANE)
+            return fail(RT_ERR_INVALID, "object " + std::to_string(i) + ": unknown kind");
+        if (o.texture < -1 || o.texture >= desc->n_textures)
+            return fail(RT_ERR_INVALID, "object " + std::to_string(i) + ": texture index out of range");
+    }
+    s->objects.assign(desc->objects, desc->objects + n);
+    s->textures.assign(desc->textures, desc->textures + desc->n_textures);
+    s->shadow_begin = desc->shadow_begin;
+    s->shadow_end = desc->shadow_end;
+    for (int c = 0; c < 3; ++c) s->null_color[c] = desc->null_color[c];
+    return RT_OK;
+}
+
+/* (re)upload the packed tables */
+int upload_scene(rt_scene *s) {
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->d_image) { HIP_TRY(hipFree(s->d_image)); s->d_image = nullptr; }
+    if (s->d_runs) { HIP_TRY(hipFree(s->d_runs)); s->d_runs = nullptr; }
+    if (s->d_shadow_runs) { HIP_TRY(hipFree(s->d_shadow_runs)); s->d_shadow_runs = nullptr; }
+    hipEvent_t t0, t1;
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(hipEventRecord(t0, nullptr));
+    const size_t image_bytes = s->image.size() * sizeof(Quad);
+    HIP_TRY(hipMalloc(&s->d_image, image_bytes));
+    HIP_TRY(hipMalloc(&s->d_runs, (s->runs.size() + 1) * sizeof(RtRun)));
+    HIP_TRY(hipMalloc(&s->d_shadow_runs, (s->shadow_runs.size() + 1) * sizeof(RtRun)));
+    HIP_TRY(hipMemcpy(s->d_image, s->image.data(), image_bytes, hipMemcpyHostToDevice));
+    if (!s->runs.empty())
+        HIP_TRY(hipMemcpy(s->d_runs, s->runs.data(), s->runs.size() * sizeof(RtRun), hipMemcpyHostToDevice));
+    if (!s->shadow_runs.empty())
+        HIP_TRY(hipMemcpy(s->d_shadow_runs, s->shadow_runs.data(), s->shadow_runs.size() * sizeof(RtRun),
+                          hipMemcpyHostToDevice));
+    HIP_TRY(hipEventRecord(t1, nullptr));
+    HIP_TRY(hipEventSynchronize(t1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+    s->timing.last_upload_ms = ms;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
     return RT_OK;
 }
 
@@ -323,44 +499,18 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     *out = nullptr;
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_ERR_INVALID, "out of memory");
-    int rc = pack_scene(desc, s);
+    int rc = adopt_desc(desc, s);
+    if (rc == RT_OK) rc = pack_scene(s);
     if (rc) { delete s; return rc; }
     s->device = device;
-    auto bail = [&](int code) { rt_scene_destroy(s); return code; };
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return bail(fail(RT_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)"));
-    if (device < 0 || device >= ndev) return bail(fail(RT_ERR_INVALID, "device index out of range"));
-#define HIP_TRY_B(expr)                                                                        \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return bail(fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
-    } while (0)
-    HIP_TRY_B(hipSetDevice(device));
-    hipEvent_t t0, t1;
-    HIP_TRY_B(hipEventCreate(&t0));
-    HIP_TRY_B(hipEventCreate(&t1));
-    HIP_TRY_B(hipEventRecord(t0, nullptr));
-    const size_t image_bytes = s->image.size() * sizeof(Quad);
-    const size_t run_bytes = (s->runs.size() + 1) * sizeof(RtRun);
-    const size_t srun_bytes = (s->shadow_runs.size() + 1) * sizeof(RtRun);
-    HIP_TRY_B(hipMalloc(&s->d_image, image_bytes));
-    HIP_TRY_B(hipMalloc(&s->d_runs, run_bytes));
-    HIP_TRY_B(hipMalloc(&s->d_shadow_runs, srun_bytes));
-    HIP_TRY_B(hipMemcpy(s->d_image, s->image.data(), image_bytes, hipMemcpyHostToDevice));
-    if (!s->runs.empty())
-        HIP_TRY_B(hipMemcpy(s->d_runs, s->runs.data(), s->runs.size() * sizeof(RtRun), hipMemcpyHostToDevice));
-    if (!s->shadow_runs.empty())
-        HIP_TRY_B(hipMemcpy(s->d_shadow_runs, s->shadow_runs.data(), s->shadow_runs.size() * sizeof(RtRun),
-                            hipMemcpyHostToDevice));
-    HIP_TRY_B(hipEventRecord(t1, nullptr));
-    HIP_TRY_B(hipEventSynchronize(t1));
-    float ms = 0.f;
-    HIP_TRY_B(hipEventElapsedTime(&ms, t0, t1));
-    s->timing.last_upload_ms = ms;
-    hipEventDestroy(t0);
-    hipEventDestroy(t1);
-#undef HIP_TRY_B
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        delete s;
+        return fail(RT_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
+    }
+    if (device < 0 || device >= ndev) { delete s; return fail(RT_ERR_INVALID, "device index out of range"); }
+    rc = upload_scene(s);
+    if (rc) { rt_scene_destroy(s); return rc; }
     *out = s;
     return RT_OK;
 }
@@ -369,11 +519,11 @@ int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     if (s->d_image || s->d_fb || s->ev_ready) (void)hipSetDevice(s->device);
     if (s->ev_ready)
-        for (int i = 0; i < kEventRing; ++i) { hipEventDestroy(s->ev[i].start); hipEventDestroy(s->ev[i].stop); }
-    if (s->d_image) hipFree(s->d_image);
-    if (s->d_runs) hipFree(s->d_runs);
-    if (s->d_shadow_runs) hipFree(s->d_shadow_runs);
-    if (s->d_fb) hipFree(s->d_fb);
+        for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].stop); }
+    if (s->d_image) (void)hipFree(s->d_image);
+    if (s->d_runs) (void)hipFree(s->d_runs);
+    if (s->d_shadow_runs) (void)hipFree(s->d_shadow_runs);
+    if (s->d_fb) (void)hipFree(s->d_fb);
     delete s;
     return RT_OK;
 }
@@ -413,8 +563,8 @@ int rt_render(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int 
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
         s->timing.last_download_ms = ms;
-        hipEventDestroy(t0);
-        hipEventDestroy(t1);
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
     }
     HIP_TRY(hipDeviceSynchronize());
     return RT_OK;
@@ -468,6 +618,15 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         if (value != 0 && (value < 64 || value > 256 || (value % 64) != 0))
             return fail(RT_ERR_INVALID, "block_threads must be 0 (auto), 64, 128, 192 or 256");
         s->block_threads_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "cluster_leaf")) {
+        if (value < 0 || value > 256) return fail(RT_ERR_INVALID, "cluster_leaf must be in [0, 256]");
+        const int old = s->cluster_leaf;
+        s->cluster_leaf = value;
+        int rc = pack_scene(s);
+        if (rc == RT_OK) rc = upload_scene(s);
+        if (rc) { s->cluster_leaf = old; return rc; }
         return RT_OK;
     }
     return fail(RT_ERR_INVALID, std::string("unknown option: ") + key);

@@ -139,6 +139,40 @@ __device__ __forceinline__ void finite_plane_distance(const float4 *g, const V3 
     }
 }
 
+/* Conservative leaf test for clustered sphere runs (rt_tables.h).  The leaf's
+ * ball (centre C, radius R, already inflated by 1 % + 1e-4 on the host)
+ * contains every member sphere.  A member can only be a CANDIDATE of
+ * sphere_distance() -- computed v >= 0 and computed d^2 >= 1e-9 -- if, with
+ * D = |c_i - o| <= DC + R:
+ *   perpendicular distance of c_i to the ray line  <= r_i + 1.2e-3 * D
+ *       (the float evaluation of r^2 - (OE.OE - v*v) is off by at most
+ *        ~17 * 2^-24 * (D^2 + r^2), and |d|^2 = 1 +- 4e-7),
+ *   (c_i - o).d >= -2.4e-7 * D.
+ * Hence every member fails unless the centre's perpendicular distance P and
+ * projection Vc satisfy  P <= R + 1.2e-3 (DC + R)  and  Vc >= -R - 2.4e-7 (DC + R).
+ * The tests below use four-fold looser constants and are themselves evaluated
+ * in float with slack for their own rounding (8e-6 * DC^2 on P^2).  All
+ * comparisons are written so that a NaN anywhere means "needed".  For shadow
+ * rays a member blocks only if its distance v - sqrt(d^2) < dist_to_light, and
+ * that distance is >= Vc - R - 1.3e-3 (DC + R); the nearest scan uses the same
+ * bound against the nearest distance so far (which may be negative, hence the
+ * |.| in the relative slack).
+ * Lanes that do not need a leaf may still run its member tests (the guard is
+ * wave-level); by the argument above those tests find nothing. */
+__device__ __forceinline__ bool cluster_needed(const float4 c0, const V3 o, const V3 d, const float max_dist) {
+    const V3 OC = mk(c0.x - o.x, c0.y - o.y, c0.z - o.z);
+    const float Vc = dot3(OC, d);
+    const float DC2 = dot3(OC, OC);
+    const float P2 = DC2 - Vc * Vc;
+    const float DC = sqrtf(DC2) * 1.001f;
+    const float reach = c0.w + 4.0e-3f * DC;
+    const bool miss_line = P2 > reach * reach + 8.0e-6f * DC2;
+    const bool behind = Vc < -(c0.w + 1.0e-5f * DC);
+    const float far = max_dist + c0.w;
+    const bool beyond = Vc > far + 1.0e-3f * fabsf(far) + 4.0e-3f * DC;
+    return !(miss_line || behind || beyond);
+}
+
 /* getCollision, src/RayTracer.cpp:50-89: first strictly-smaller distance in
  * Scene index order wins; "infinity" is 65535. */
 __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__restrict__ runs,
@@ -155,6 +189,28 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
                 bool hit; float t;
                 sphere_distance(g[i], o, d, &hit, &t);
                 if (hit && t < best) { best = t; best_idx = run.first + i; }
+            }
+        } else if (run.kind == RT_KIND_SPHERE_CLUSTERED) {
+            /* leaves in any order: ties go to the lower Scene index, which is
+             * what the in-order scan with a strict `<` yields */
+            const uint32_t *cidx = reinterpret_cast<const uint32_t *>(lds) + run.first;
+            for (int c = 0; c < run.count; ++c) {
+                const float4 c0 = g[c * RT_CLUSTER_QUADS];
+                /* a hit beyond the nearest so far cannot win: its distance is >= Vc - R - fuzz */
+                if (!wave_any(cluster_needed(c0, o, d, best))) continue;
+                const float4 c1 = g[c * RT_CLUSTER_QUADS + 1];
+                const float4 *m = lds + __float_as_uint(c1.x);
+                const int n = (int)__float_as_uint(c1.y);
+                const uint32_t *ids = cidx + __float_as_uint(c1.z);
+#pragma unroll 2
+                for (int i = 0; i < n; ++i) {
+                    bool hit; float t;
+                    sphere_distance(m[i], o, d, &hit, &t);
+                    if (wave_any(hit)) {
+                        const int idx = (int)ids[i];
+                        if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
+                    }
+                }
             }
         } else if (run.kind == RT_KIND_INFINITE_PLANE) {
             for (int i = 0; i < run.count; ++i) {
@@ -193,6 +249,21 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restr
                 blocked = blocked || (hit && t < dist_to_light);
                 if (i + 1 < run.count) {
                     sphere_distance(g[i + 1], o, d, &hit, &t);
+                    blocked = blocked || (hit && t < dist_to_light);
+                }
+            }
+        } else if (run.kind == RT_KIND_SPHERE_CLUSTERED) {
+            for (int c = 0; c < run.count; ++c) {
+                if (!wave_any(!blocked)) break;
+                const float4 c0 = g[c * RT_CLUSTER_QUADS];
+                if (!wave_any(!blocked && cluster_needed(c0, o, d, dist_to_light))) continue;
+                const float4 c1 = g[c * RT_CLUSTER_QUADS + 1];
+                const float4 *m = lds + __float_as_uint(c1.x);
+                const int n = (int)__float_as_uint(c1.y);
+#pragma unroll 2
+                for (int i = 0; i < n; ++i) {
+                    bool hit; float t;
+                    sphere_distance(m[i], o, d, &hit, &t);
                     blocked = blocked || (hit && t < dist_to_light);
                 }
             }

@@ -22,6 +22,18 @@
  *   textures   2 quads per checkerboard: {light.rgb, width}, {dark.rgb, height}
  *   objinfo    one u32 per object (4 per quad):
  *                bits 0-15 geometry offset (quads), 16-17 kind, 20-31 material row
+ *   cidx       one u32 per clustered sphere: its Scene index (member order)
+ *
+ * Clustered sphere runs.  A run of >= 4*leaf spheres is regrouped into spatial
+ * leaves of <= leaf spheres; the spheres' geometry quads are stored leaf by
+ * leaf (objinfo still finds each one) and a cluster table (between geometry
+ * and lights) holds 2 quads per leaf:
+ *                {centre.xyz, inflated bounding radius},
+ *                {bits(member geometry offset), bits(member count),
+ *                 bits(first slot in the run's cidx table), 0}
+ * The bounding ball contains every member sphere.  Nearest-hit stays exact
+ * because ties are broken on the Scene index (lexicographic min of (distance,
+ * index) is what an in-order scan with a strict `<` computes).
  *
  * The object list is additionally described as RUNS of consecutive objects of
  * one kind and one light flag (an int4 each, kept in global memory and read
@@ -41,6 +53,11 @@
 #define RT_LIGHT_QUADS  2
 #define RT_MAT_QUADS    2
 #define RT_TEX_QUADS    2
+#define RT_CLUSTER_QUADS 2
+
+/* run kinds: RT_KIND_* of rt_capi.h (0 sphere, 1 infinite plane, 2 finite
+ * plane) plus a long sphere run regrouped into spatial clusters */
+#define RT_KIND_SPHERE_CLUSTERED 3
 
 #define RT_MAX_GEOM_QUADS 65535   /* 16-bit geometry offset in objinfo */
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
@@ -50,9 +67,9 @@
 
 typedef struct RtRun {
     int32_t kind;       /* RT_KIND_*                               */
-    int32_t count;      /* objects in the run                      */
-    int32_t first;      /* Scene index of the first object         */
-    int32_t geom_off;   /* quad offset of the first object's record */
+    int32_t count;      /* objects in the run; clustered: leaves   */
+    int32_t first;      /* Scene index of the first object; clustered: u32 index of the run's cidx table */
+    int32_t geom_off;   /* quad offset of the first object's record; clustered: of the cluster table     */
 } RtRun;
 
 typedef struct RtParams {

@@ -30,6 +30,55 @@ def alloc_full(W, H, world, device, dtype=torch.float32):
     return full, views
 
 
-def gather_strips(strip_buf, views, dst=0):
-    """Gather every rank's strip buffer into rank `dst`'s views (None elsewhere)."""
-    dist.gather(strip_buf, views if dist.get_rank() == dst else None, dst=dst)
+def gather_strips(strip_buf, views, dst=0, async_op=False):
+    """Gather every rank's strip buffer into rank `dst`'s views (None elsewhere).
+    With async_op the collective runs on the backend's own stream and the
+    returned work handle must be wait()ed before strip_buf is written again."""
+    return dist.gather(strip_buf, views if dist.get_rank() == dst else None, dst=dst, async_op=async_op)
+
+
+class StripPipeline:
+    """Render/gather software pipeline over successive frames.
+
+    Frames are independent, so while RCCL moves frame k's strips to rank 0 (on
+    its own stream, over xGMI) the render kernel of frame k+1 already runs on
+    the compute stream.  Two strip buffers alternate; a buffer is rendered into
+    again only after the gather that read it has completed.  `render(buf)` is
+    the caller's function that enqueues the kernel writing `buf`.
+    """
+
+    def __init__(self, W, H, world, rank, device, render, overlap=True, dtype=torch.float32):
+        self.world, self.rank, self.render, self.overlap = world, rank, render, overlap
+        self.x0, self.x1, self.strip = strip_bounds(W, world, rank)
+        n_buf = 2 if (overlap and world > 1) else 1
+        self.bufs = [torch.empty((self.strip, H, 3), dtype=dtype, device=device) for _ in range(n_buf)]
+        self.pending = [None] * n_buf
+        self.full, self.views = (alloc_full(W, H, world, device, dtype) if (world > 1 and rank == 0)
+                                 else (None, None))
+        self.k = 0
+
+    def step(self):
+        b = self.k % len(self.bufs)
+        self.k += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        self.render(self.bufs[b])
+        if self.world > 1:
+            if self.overlap:
+                self.pending[b] = gather_strips(self.bufs[b], self.views, dst=0, async_op=True)
+            else:
+                gather_strips(self.bufs[b], self.views, dst=0)
+
+    def drain(self):
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
+
+    def image(self, W):
+        """Rank 0: the gathered framebuffer (first W columns); single GPU: the strip."""
+        self.drain()
+        if self.world == 1:
+            return self.bufs[(self.k - 1) % len(self.bufs)]
+        return self.full[:W] if self.full is not None else None
