@@ -69,6 +69,7 @@ struct rt_scene {
     int tile_z_log2 = 2;          /* 16 columns x 4 rows per wavefront (measured best on MI355X: wide tiles diverge least) */
     int block_threads_opt = 0;    /* 0 = auto */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
+    int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
     int n_clusters = 0;
     /* timing */
     EventPair ev[kEventRing];
@@ -146,7 +147,7 @@ int pack_scene(rt_scene *s) {
     const rt_object_desc *objs = s->objects.data();
     const int sb = s->shadow_begin, se = s->shadow_end;
 
-    std::vector<Quad> geom, lights, mats, texs, clusters;
+    std::vector<Quad> geom, lights, mats, texs, clusters, groups;
     std::vector<uint32_t> objinfo((size_t)n, 0u), cidx;
     std::vector<int> geom_off((size_t)n, 0), mat_of((size_t)n, 0);
     std::map<std::vector<uint32_t>, int> mat_index;
@@ -229,22 +230,38 @@ int pack_scene(rt_scene *s) {
             for (int i = 0; i < sp.count; ++i) ids[(size_t)i] = first + i;
             std::vector<Leaf> leaves;
             split_leaves(objs, ids, s->cluster_leaf, leaves);
-            const int cluster_first = (int)(clusters.size() / RT_CLUSTER_QUADS);
+            /* leaves come out of the k-d split in spatial order: every `group`
+             * consecutive leaves form a group with its own bounding ball */
+            const int G = std::max(1, s->cluster_group);
+            const int n_groups = ((int)leaves.size() + G - 1) / G;
+            const int group_first = (int)(groups.size() / RT_CLUSTER_QUADS);
             const int cidx_first = (int)cidx.size();
-            for (const Leaf &L : leaves) {
-                const int member_off = (int)geom.size();
-                const int slot = (int)cidx.size() - cidx_first;
-                for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); }
-                clusters.push_back({{L.c[0], L.c[1], L.c[2], L.rm}});
-                clusters.push_back({{bits_to_float((uint32_t)member_off), bits_to_float((uint32_t)L.members.size()),
-                                     bits_to_float((uint32_t)slot), 0.0f}});
+            for (int gi = 0; gi < n_groups; ++gi) {
+                const int l0 = gi * G, l1 = std::min((int)leaves.size(), l0 + G);
+                std::vector<int> all;
+                for (int l = l0; l < l1; ++l) all.insert(all.end(), leaves[(size_t)l].members.begin(), leaves[(size_t)l].members.end());
+                std::vector<Leaf> ball;
+                make_leaf(objs, all, ball);
+                groups.push_back({{ball[0].c[0], ball[0].c[1], ball[0].c[2], ball[0].rm}});
+                /* leaf table offset is relative to the leaf section; patched to absolute below */
+                groups.push_back({{bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS)),
+                                   bits_to_float((uint32_t)(l1 - l0)), 0.0f, 0.0f}});
+                for (int l = l0; l < l1; ++l) {
+                    const Leaf &L = leaves[(size_t)l];
+                    const int member_off = (int)geom.size();
+                    const int slot = (int)cidx.size() - cidx_first;
+                    for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); }
+                    clusters.push_back({{L.c[0], L.c[1], L.c[2], L.rm}});
+                    clusters.push_back({{bits_to_float((uint32_t)member_off), bits_to_float((uint32_t)L.members.size()),
+                                         bits_to_float((uint32_t)slot), 0.0f}});
+                }
             }
             s->n_clusters += (int)leaves.size();
-            pending.push_back(Pending{s->runs.size(), false, cluster_first, cidx_first});
-            s->runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, (int)leaves.size(), 0, 0});
+            pending.push_back(Pending{s->runs.size(), false, group_first, cidx_first});
+            s->runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, n_groups, 0, 0});
             if (in_shadow_all) {
-                pending.push_back(Pending{s->shadow_runs.size(), true, cluster_first, cidx_first});
-                s->shadow_runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, (int)leaves.size(), 0, 0});
+                pending.push_back(Pending{s->shadow_runs.size(), true, group_first, cidx_first});
+                s->shadow_runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, n_groups, 0, 0});
             }
         } else {
             for (int i = first; i < last; ++i) emit_geometry(i);
@@ -281,6 +298,13 @@ int pack_scene(rt_scene *s) {
     s->image.insert(s->image.end(), geom.begin(), geom.end());
     const int clusters_off = (int)s->image.size();
     s->image.insert(s->image.end(), clusters.begin(), clusters.end());
+    const int groups_off = (int)s->image.size();
+    for (size_t k = 1; k < groups.size(); k += RT_CLUSTER_QUADS) {      /* leaf index -> absolute quad offset */
+        uint32_t leaf_index;
+        std::memcpy(&leaf_index, &groups[k].v[0], 4);
+        groups[k].v[0] = bits_to_float((uint32_t)(clusters_off + (int)leaf_index * RT_CLUSTER_QUADS));
+    }
+    s->image.insert(s->image.end(), groups.begin(), groups.end());
     b.lights_off = (int)s->image.size();
     s->image.insert(s->image.end(), lights.begin(), lights.end());
     b.mat_off = (int)s->image.size();
@@ -295,7 +319,7 @@ int pack_scene(rt_scene *s) {
     if (!cidx.empty()) std::memcpy(s->image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
     for (const Pending &pd : pending) {
         RtRun &run = pd.shadow ? s->shadow_runs[pd.run_pos] : s->runs[pd.run_pos];
-        run.geom_off = clusters_off + pd.cluster_first * RT_CLUSTER_QUADS;
+        run.geom_off = groups_off + pd.cluster_first * RT_CLUSTER_QUADS;
         run.first = cidx_off * 4 + pd.cidx_first;          /* u32 index of the run's member-index table */
     }
     if (s->image.empty()) s->image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
@@ -620,13 +644,15 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         s->block_threads_opt = value;
         return RT_OK;
     }
-    if (!std::strcmp(key, "cluster_leaf")) {
-        if (value < 0 || value > 256) return fail(RT_ERR_INVALID, "cluster_leaf must be in [0, 256]");
-        const int old = s->cluster_leaf;
-        s->cluster_leaf = value;
+    if (!std::strcmp(key, "cluster_leaf") || !std::strcmp(key, "cluster_group")) {
+        const bool leaf = !std::strcmp(key, "cluster_leaf");
+        if (value < (leaf ? 0 : 1) || value > 256) return fail(RT_ERR_INVALID, "cluster_leaf in [0,256], cluster_group in [1,256]");
+        int &field = leaf ? s->cluster_leaf : s->cluster_group;
+        const int old = field;
+        field = value;
         int rc = pack_scene(s);
         if (rc == RT_OK) rc = upload_scene(s);
-        if (rc) { s->cluster_leaf = old; return rc; }
+        if (rc) { field = old; return rc; }
         return RT_OK;
     }
     return fail(RT_ERR_INVALID, std::string("unknown option: ") + key);

@@ -194,21 +194,26 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
             /* leaves in any order: ties go to the lower Scene index, which is
              * what the in-order scan with a strict `<` yields */
             const uint32_t *cidx = reinterpret_cast<const uint32_t *>(lds) + run.first;
-            for (int c = 0; c < run.count; ++c) {
-                const float4 c0 = g[c * RT_CLUSTER_QUADS];
+            for (int gi = 0; gi < run.count; ++gi) {
                 /* a hit beyond the nearest so far cannot win: its distance is >= Vc - R - fuzz */
-                if (!wave_any(cluster_needed(c0, o, d, best))) continue;
-                const float4 c1 = g[c * RT_CLUSTER_QUADS + 1];
-                const float4 *m = lds + __float_as_uint(c1.x);
-                const int n = (int)__float_as_uint(c1.y);
-                const uint32_t *ids = cidx + __float_as_uint(c1.z);
+                if (!wave_any(cluster_needed(g[gi * RT_CLUSTER_QUADS], o, d, best))) continue;
+                const float4 g1 = g[gi * RT_CLUSTER_QUADS + 1];
+                const float4 *leaves = lds + __float_as_uint(g1.x);
+                const int n_leaves = (int)__float_as_uint(g1.y);
+                for (int c = 0; c < n_leaves; ++c) {
+                    if (!wave_any(cluster_needed(leaves[c * RT_CLUSTER_QUADS], o, d, best))) continue;
+                    const float4 c1 = leaves[c * RT_CLUSTER_QUADS + 1];
+                    const float4 *m = lds + __float_as_uint(c1.x);
+                    const int n = (int)__float_as_uint(c1.y);
+                    const uint32_t *ids = cidx + __float_as_uint(c1.z);
 #pragma unroll 2
-                for (int i = 0; i < n; ++i) {
-                    bool hit; float t;
-                    sphere_distance(m[i], o, d, &hit, &t);
-                    if (wave_any(hit)) {
-                        const int idx = (int)ids[i];
-                        if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
+                    for (int i = 0; i < n; ++i) {
+                        bool hit; float t;
+                        sphere_distance(m[i], o, d, &hit, &t);
+                        if (wave_any(hit)) {
+                            const int idx = (int)ids[i];
+                            if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
+                        }
                     }
                 }
             }
@@ -253,18 +258,23 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restr
                 }
             }
         } else if (run.kind == RT_KIND_SPHERE_CLUSTERED) {
-            for (int c = 0; c < run.count; ++c) {
+            for (int gi = 0; gi < run.count; ++gi) {
                 if (!wave_any(!blocked)) break;
-                const float4 c0 = g[c * RT_CLUSTER_QUADS];
-                if (!wave_any(!blocked && cluster_needed(c0, o, d, dist_to_light))) continue;
-                const float4 c1 = g[c * RT_CLUSTER_QUADS + 1];
-                const float4 *m = lds + __float_as_uint(c1.x);
-                const int n = (int)__float_as_uint(c1.y);
+                if (!wave_any(!blocked && cluster_needed(g[gi * RT_CLUSTER_QUADS], o, d, dist_to_light))) continue;
+                const float4 g1 = g[gi * RT_CLUSTER_QUADS + 1];
+                const float4 *leaves = lds + __float_as_uint(g1.x);
+                const int n_leaves = (int)__float_as_uint(g1.y);
+                for (int c = 0; c < n_leaves; ++c) {
+                    if (!wave_any(!blocked && cluster_needed(leaves[c * RT_CLUSTER_QUADS], o, d, dist_to_light))) continue;
+                    const float4 c1 = leaves[c * RT_CLUSTER_QUADS + 1];
+                    const float4 *m = lds + __float_as_uint(c1.x);
+                    const int n = (int)__float_as_uint(c1.y);
 #pragma unroll 2
-                for (int i = 0; i < n; ++i) {
-                    bool hit; float t;
-                    sphere_distance(m[i], o, d, &hit, &t);
-                    blocked = blocked || (hit && t < dist_to_light);
+                    for (int i = 0; i < n; ++i) {
+                        bool hit; float t;
+                        sphere_distance(m[i], o, d, &hit, &t);
+                        blocked = blocked || (hit && t < dist_to_light);
+                    }
                 }
             }
         } else if (run.kind == RT_KIND_INFINITE_PLANE) {

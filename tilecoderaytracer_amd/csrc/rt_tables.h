@@ -31,7 +31,11 @@
  *                {centre.xyz, inflated bounding radius},
  *                {bits(member geometry offset), bits(member count),
  *                 bits(first slot in the run's cidx table), 0}
- * The bounding ball contains every member sphere.  Nearest-hit stays exact
+ * Leaves come out of the split in spatial order; every `group` consecutive
+ * leaves form a GROUP with its own ball (group table after the leaf table, 2
+ * quads: {centre.xyz, inflated radius}, {bits(quad offset of its first leaf
+ * record), bits(leaf count), 0, 0}).  A clustered run lists its groups.
+ * Each ball contains every member sphere.  Nearest-hit stays exact
  * because ties are broken on the Scene index (lexicographic min of (distance,
  * index) is what an in-order scan with a strict `<` computes).
  *
@@ -67,9 +71,9 @@
 
 typedef struct RtRun {
     int32_t kind;       /* RT_KIND_*                               */
-    int32_t count;      /* objects in the run; clustered: leaves   */
+    int32_t count;      /* objects in the run; clustered: groups   */
     int32_t first;      /* Scene index of the first object; clustered: u32 index of the run's cidx table */
-    int32_t geom_off;   /* quad offset of the first object's record; clustered: of the cluster table     */
+    int32_t geom_off;   /* quad offset of the first object's record; clustered: of the group table       */
 } RtRun;
 
 typedef struct RtParams {
