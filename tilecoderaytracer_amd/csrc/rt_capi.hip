@@ -88,30 +88,25 @@ namespace {
  * contains every member sphere; the kernel skips a leaf only when a
  * conservative test proves no member can be a candidate hit, so results are
  * unchanged (rt_kernel.hip, cluster_needed()). */
-struct Leaf { std::vector<int> members; float c[3]; float rm; };
+struct Leaf { std::vector<int> members; float lo[3], hi[3]; };
 
 void make_leaf(const rt_object_desc *objs, const std::vector<int> &ids, std::vector<Leaf> &out) {
     Leaf L;
     L.members = ids;
+    /* axis-aligned box around every member sphere (centre +- |radius|) */
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int i : ids)
         for (int k = 0; k < 3; ++k) {
-            lo[k] = std::min(lo[k], (double)objs[i].origin[k]);
-            hi[k] = std::max(hi[k], (double)objs[i].origin[k]);
+            const double r = std::fabs((double)objs[i].radius);
+            lo[k] = std::min(lo[k], (double)objs[i].origin[k] - r);
+            hi[k] = std::max(hi[k], (double)objs[i].origin[k] + r);
         }
-    for (int k = 0; k < 3; ++k) L.c[k] = (float)(0.5 * (lo[k] + hi[k]));
-    /* radius measured from the float-rounded centre the kernel will use */
-    double R = 0.0;
-    for (int i : ids) {
-        double d2 = 0.0;
-        for (int k = 0; k < 3; ++k) {
-            const double d = (double)objs[i].origin[k] - (double)L.c[k];
-            d2 += d * d;
-        }
-        R = std::max(R, std::sqrt(d2) + std::fabs((double)objs[i].radius));
+    /* inflate by 1 % of the largest extent + 1e-4, then round outwards to float */
+    const double pad = 0.01 * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])) + 1e-4;
+    for (int k = 0; k < 3; ++k) {
+        L.lo[k] = std::nextafter((float)(lo[k] - pad), -INFINITY);
+        L.hi[k] = std::nextafter((float)(hi[k] + pad), INFINITY);
     }
-    /* inflate: 1 % + an absolute term, then round up to float */
-    L.rm = std::nextafter((float)(R * 1.01 + 1e-4), INFINITY);
     out.push_back(std::move(L));
 }
 
@@ -242,18 +237,18 @@ int pack_scene(rt_scene *s) {
                 for (int l = l0; l < l1; ++l) all.insert(all.end(), leaves[(size_t)l].members.begin(), leaves[(size_t)l].members.end());
                 std::vector<Leaf> ball;
                 make_leaf(objs, all, ball);
-                groups.push_back({{ball[0].c[0], ball[0].c[1], ball[0].c[2], ball[0].rm}});
                 /* leaf table offset is relative to the leaf section; patched to absolute below */
-                groups.push_back({{bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS)),
-                                   bits_to_float((uint32_t)(l1 - l0)), 0.0f, 0.0f}});
+                groups.push_back({{ball[0].lo[0], ball[0].lo[1], ball[0].lo[2],
+                                   bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS))}});
+                groups.push_back({{ball[0].hi[0], ball[0].hi[1], ball[0].hi[2], bits_to_float((uint32_t)(l1 - l0))}});
                 for (int l = l0; l < l1; ++l) {
                     const Leaf &L = leaves[(size_t)l];
                     const int member_off = (int)geom.size();
                     const int slot = (int)cidx.size() - cidx_first;
                     for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); }
-                    clusters.push_back({{L.c[0], L.c[1], L.c[2], L.rm}});
-                    clusters.push_back({{bits_to_float((uint32_t)member_off), bits_to_float((uint32_t)L.members.size()),
-                                         bits_to_float((uint32_t)slot), 0.0f}});
+                    clusters.push_back({{L.lo[0], L.lo[1], L.lo[2],
+                                         bits_to_float((uint32_t)member_off | ((uint32_t)L.members.size() << 16))}});
+                    clusters.push_back({{L.hi[0], L.hi[1], L.hi[2], bits_to_float((uint32_t)slot)}});
                 }
             }
             s->n_clusters += (int)leaves.size();
@@ -299,10 +294,10 @@ int pack_scene(rt_scene *s) {
     const int clusters_off = (int)s->image.size();
     s->image.insert(s->image.end(), clusters.begin(), clusters.end());
     const int groups_off = (int)s->image.size();
-    for (size_t k = 1; k < groups.size(); k += RT_CLUSTER_QUADS) {      /* leaf index -> absolute quad offset */
+    for (size_t k = 0; k < groups.size(); k += RT_CLUSTER_QUADS) {      /* leaf index -> absolute quad offset */
         uint32_t leaf_index;
-        std::memcpy(&leaf_index, &groups[k].v[0], 4);
-        groups[k].v[0] = bits_to_float((uint32_t)(clusters_off + (int)leaf_index * RT_CLUSTER_QUADS));
+        std::memcpy(&leaf_index, &groups[k].v[3], 4);
+        groups[k].v[3] = bits_to_float((uint32_t)(clusters_off + (int)leaf_index * RT_CLUSTER_QUADS));
     }
     s->image.insert(s->image.end(), groups.begin(), groups.end());
     b.lights_off = (int)s->image.size();
@@ -646,7 +641,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     }
     if (!std::strcmp(key, "cluster_leaf") || !std::strcmp(key, "cluster_group")) {
         const bool leaf = !std::strcmp(key, "cluster_leaf");
-        if (value < (leaf ? 0 : 1) || value > 256) return fail(RT_ERR_INVALID, "cluster_leaf in [0,256], cluster_group in [1,256]");
+        if (value < (leaf ? 0 : 1) || value > 255) return fail(RT_ERR_INVALID, "cluster_leaf in [0,255], cluster_group in [1,255]");
         int &field = leaf ? s->cluster_leaf : s->cluster_group;
         const int old = field;
         field = value;

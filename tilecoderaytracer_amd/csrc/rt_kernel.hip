@@ -139,38 +139,47 @@ __device__ __forceinline__ void finite_plane_distance(const float4 *g, const V3 
     }
 }
 
-/* Conservative leaf test for clustered sphere runs (rt_tables.h).  The leaf's
- * ball (centre C, radius R, already inflated by 1 % + 1e-4 on the host)
+/* Conservative box test for clustered sphere runs (rt_tables.h).  The box
+ * [lo, hi] (already inflated on the host by 1 % of its largest extent + 1e-4)
  * contains every member sphere.  A member can only be a CANDIDATE of
  * sphere_distance() -- computed v >= 0 and computed d^2 >= 1e-9 -- if, with
- * D = |c_i - o| <= DC + R:
- *   perpendicular distance of c_i to the ray line  <= r_i + 1.2e-3 * D
- *       (the float evaluation of r^2 - (OE.OE - v*v) is off by at most
- *        ~17 * 2^-24 * (D^2 + r^2), and |d|^2 = 1 +- 4e-7),
- *   (c_i - o).d >= -2.4e-7 * D.
- * Hence every member fails unless the centre's perpendicular distance P and
- * projection Vc satisfy  P <= R + 1.2e-3 (DC + R)  and  Vc >= -R - 2.4e-7 (DC + R).
- * The tests below use four-fold looser constants and are themselves evaluated
- * in float with slack for their own rounding (8e-6 * DC^2 on P^2).  All
- * comparisons are written so that a NaN anywhere means "needed".  For shadow
- * rays a member blocks only if its distance v - sqrt(d^2) < dist_to_light, and
- * that distance is >= Vc - R - 1.3e-3 (DC + R); the nearest scan uses the same
- * bound against the nearest distance so far (which may be negative, hence the
- * |.| in the relative slack).
- * Lanes that do not need a leaf may still run its member tests (the guard is
+ * D = |c_i - o|:
+ *   the ray LINE passes within  r_eff = sqrt(r_i^2 + 1.4e-6 D^2) <= r_i + 1.2e-3 D
+ *   of c_i  (the float evaluation of r^2 - (OE.OE - v*v) is off by at most
+ *   ~17 * 2^-24 * (D^2 + r^2), and |d|^2 = 1 +- 4e-7), and
+ *   the parameter of closest approach v_i >= -2.4e-7 D;
+ * and its reported distance v - sqrt(d^2) is >= the parameter at which the ray
+ * enters the ball B(c_i, r_eff), minus 2.4e-7 D.
+ * Every such ball lies inside the box grown by `ex` = 4e-3 * far, where
+ * far >= D is the L1 distance from the origin to the box's farthest corner.
+ * So a slab test of the ray against the grown box decides: no intersection, or
+ * exit behind the origin, or entry beyond `max_dist` (nearest distance so far /
+ * distance to the light) => no member can matter.  The slab arithmetic itself
+ * carries relative slack 1e-5; 1/d may be approximate (v_rcp).  A NaN in the
+ * ray makes every member test fail in the reference too, and every comparison
+ * below is written so that a NaN bound means "needed".
+ * Lanes that do not need a box may still run its member tests (the guard is
  * wave-level); by the argument above those tests find nothing. */
-__device__ __forceinline__ bool cluster_needed(const float4 c0, const V3 o, const V3 d, const float max_dist) {
-    const V3 OC = mk(c0.x - o.x, c0.y - o.y, c0.z - o.z);
-    const float Vc = dot3(OC, d);
-    const float DC2 = dot3(OC, OC);
-    const float P2 = DC2 - Vc * Vc;
-    const float DC = sqrtf(DC2) * 1.001f;
-    const float reach = c0.w + 4.0e-3f * DC;
-    const bool miss_line = P2 > reach * reach + 8.0e-6f * DC2;
-    const bool behind = Vc < -(c0.w + 1.0e-5f * DC);
-    const float far = max_dist + c0.w;
-    const bool beyond = Vc > far + 1.0e-3f * fabsf(far) + 4.0e-3f * DC;
-    return !(miss_line || behind || beyond);
+__device__ __forceinline__ bool box_needed(const float4 b0, const float4 b1, const V3 o, const V3 inv,
+                                           const float max_dist) {
+    const float x0 = b0.x - o.x, x1 = b1.x - o.x;
+    const float y0 = b0.y - o.y, y1 = b1.y - o.y;
+    const float z0 = b0.z - o.z, z1 = b1.z - o.z;
+    const float far = fmaxf(fabsf(x0), fabsf(x1)) + fmaxf(fabsf(y0), fabsf(y1)) + fmaxf(fabsf(z0), fabsf(z1));
+    const float ex = 4.0e-3f * far;
+    const float ax = (x0 - ex) * inv.x, bx = (x1 + ex) * inv.x;
+    const float ay = (y0 - ex) * inv.y, by = (y1 + ex) * inv.y;
+    const float az = (z0 - ex) * inv.z, bz = (z1 + ex) * inv.z;
+    const float t_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const bool miss = t_exit < t_enter - 1.0e-5f * (fabsf(t_enter) + fabsf(t_exit));
+    const bool behind = t_exit < -(1.0e-5f * fabsf(t_exit) + 1.0e-6f);
+    const bool beyond = t_enter - 1.0e-5f * fabsf(t_enter) > max_dist + 1.0e-3f * fabsf(max_dist) + 1.0e-6f;
+    return !(miss || behind || beyond);
+}
+
+__device__ __forceinline__ V3 approx_inverse(const V3 d) {
+    return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 }
 
 /* getCollision, src/RayTracer.cpp:50-89: first strictly-smaller distance in
@@ -194,18 +203,19 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
             /* leaves in any order: ties go to the lower Scene index, which is
              * what the in-order scan with a strict `<` yields */
             const uint32_t *cidx = reinterpret_cast<const uint32_t *>(lds) + run.first;
+            const V3 inv = approx_inverse(d);
             for (int gi = 0; gi < run.count; ++gi) {
-                /* a hit beyond the nearest so far cannot win: its distance is >= Vc - R - fuzz */
-                if (!wave_any(cluster_needed(g[gi * RT_CLUSTER_QUADS], o, d, best))) continue;
-                const float4 g1 = g[gi * RT_CLUSTER_QUADS + 1];
-                const float4 *leaves = lds + __float_as_uint(g1.x);
-                const int n_leaves = (int)__float_as_uint(g1.y);
+                /* a hit that enters beyond the nearest distance so far cannot win */
+                const float4 g0 = g[gi * RT_CLUSTER_QUADS], g1 = g[gi * RT_CLUSTER_QUADS + 1];
+                if (!wave_any(box_needed(g0, g1, o, inv, best))) continue;
+                const float4 *leaves = lds + __float_as_uint(g0.w);
+                const int n_leaves = (int)__float_as_uint(g1.w);
                 for (int c = 0; c < n_leaves; ++c) {
-                    if (!wave_any(cluster_needed(leaves[c * RT_CLUSTER_QUADS], o, d, best))) continue;
-                    const float4 c1 = leaves[c * RT_CLUSTER_QUADS + 1];
-                    const float4 *m = lds + __float_as_uint(c1.x);
-                    const int n = (int)__float_as_uint(c1.y);
-                    const uint32_t *ids = cidx + __float_as_uint(c1.z);
+                    const float4 c0 = leaves[c * RT_CLUSTER_QUADS], c1 = leaves[c * RT_CLUSTER_QUADS + 1];
+                    if (!wave_any(box_needed(c0, c1, o, inv, best))) continue;
+                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
+                    const int n = (int)(__float_as_uint(c0.w) >> 16);
+                    const uint32_t *ids = cidx + __float_as_uint(c1.w);
 #pragma unroll 2
                     for (int i = 0; i < n; ++i) {
                         bool hit; float t;
@@ -258,17 +268,18 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restr
                 }
             }
         } else if (run.kind == RT_KIND_SPHERE_CLUSTERED) {
+            const V3 inv = approx_inverse(d);
             for (int gi = 0; gi < run.count; ++gi) {
                 if (!wave_any(!blocked)) break;
-                if (!wave_any(!blocked && cluster_needed(g[gi * RT_CLUSTER_QUADS], o, d, dist_to_light))) continue;
-                const float4 g1 = g[gi * RT_CLUSTER_QUADS + 1];
-                const float4 *leaves = lds + __float_as_uint(g1.x);
-                const int n_leaves = (int)__float_as_uint(g1.y);
+                const float4 g0 = g[gi * RT_CLUSTER_QUADS], g1 = g[gi * RT_CLUSTER_QUADS + 1];
+                if (!wave_any(!blocked && box_needed(g0, g1, o, inv, dist_to_light))) continue;
+                const float4 *leaves = lds + __float_as_uint(g0.w);
+                const int n_leaves = (int)__float_as_uint(g1.w);
                 for (int c = 0; c < n_leaves; ++c) {
-                    if (!wave_any(!blocked && cluster_needed(leaves[c * RT_CLUSTER_QUADS], o, d, dist_to_light))) continue;
-                    const float4 c1 = leaves[c * RT_CLUSTER_QUADS + 1];
-                    const float4 *m = lds + __float_as_uint(c1.x);
-                    const int n = (int)__float_as_uint(c1.y);
+                    const float4 c0 = leaves[c * RT_CLUSTER_QUADS], c1 = leaves[c * RT_CLUSTER_QUADS + 1];
+                    if (!wave_any(!blocked && box_needed(c0, c1, o, inv, dist_to_light))) continue;
+                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
+                    const int n = (int)(__float_as_uint(c0.w) >> 16);
 #pragma unroll 2
                     for (int i = 0; i < n; ++i) {
                         bool hit; float t;

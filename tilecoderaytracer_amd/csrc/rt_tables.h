@@ -28,14 +28,13 @@
  * leaves of <= leaf spheres; the spheres' geometry quads are stored leaf by
  * leaf (objinfo still finds each one) and a cluster table (between geometry
  * and lights) holds 2 quads per leaf:
- *                {centre.xyz, inflated bounding radius},
- *                {bits(member geometry offset), bits(member count),
- *                 bits(first slot in the run's cidx table), 0}
+ *                {box lo.xyz, bits(member geometry offset | member count << 16)},
+ *                {box hi.xyz, bits(first slot in the run's cidx table)}
  * Leaves come out of the split in spatial order; every `group` consecutive
- * leaves form a GROUP with its own ball (group table after the leaf table, 2
- * quads: {centre.xyz, inflated radius}, {bits(quad offset of its first leaf
- * record), bits(leaf count), 0, 0}).  A clustered run lists its groups.
- * Each ball contains every member sphere.  Nearest-hit stays exact
+ * leaves form a GROUP with its own box (group table after the leaf table, 2
+ * quads: {lo.xyz, bits(quad offset of its first leaf record)}, {hi.xyz,
+ * bits(leaf count)}).  A clustered run lists its groups.  Each (inflated,
+ * axis-aligned) box contains every member sphere.  Nearest-hit stays exact
  * because ties are broken on the Scene index (lexicographic min of (distance,
  * index) is what an in-order scan with a strict `<` computes).
  *
