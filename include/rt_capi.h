@@ -137,6 +137,19 @@ int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, int W, int H,
 int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
                     int max_depth, int ngpu, float *out_rgb);
 
+/* Diagnostic "counting build" of rt_render (same arithmetic and control flow,
+ * plus work counters; slower).  stats[k], k < RT_STATS_COUNT:
+ *   0 nearest-hit rays (lanes)        1 shadow rays (lanes)
+ *   2 nearest-hit scans (wavefronts)  3 shadow scans (wavefronts)
+ *   4 sphere tests issued (wavefronts) 5 plane tests issued (wavefronts)
+ *   6 cluster box tests issued (wavefronts)
+ *   7 sphere tests the lane itself needed (lanes)
+ * out_rgb may be NULL.  The reference has no counterpart (its gprof figures
+ * are quoted in SURVEY.md section 3.3). */
+#define RT_STATS_COUNT 8
+int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, int x0, int x1,
+                    int max_depth, float *out_rgb, uint64_t *stats, int n_stats);
+
 int rt_get_timing(const rt_scene *scene, rt_timing *out);
 int rt_reset_timing(rt_scene *scene);
 int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);

@@ -99,12 +99,13 @@ def load_library():
     lib.rt_render.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp]
     lib.rt_render_device.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, vp]
     lib.rt_render_multi.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), i, i, i, i, vp]
+    lib.rt_render_stats.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, C.POINTER(C.c_uint64), i]
     lib.rt_get_timing.argtypes = [vp, C.POINTER(RtTiming)]
     lib.rt_reset_timing.argtypes = [vp]
     lib.rt_get_launch_info.argtypes = [vp, C.POINTER(RtLaunchInfo)]
     lib.rt_set_option.argtypes = [vp, C.c_char_p, i]
     for name in ("rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render",
-                 "rt_render_device", "rt_render_multi", "rt_get_timing", "rt_reset_timing",
+                 "rt_render_device", "rt_render_multi", "rt_render_stats", "rt_get_timing", "rt_reset_timing",
                  "rt_get_launch_info", "rt_set_option"):
         getattr(lib, name).restype = i
     _lib = lib

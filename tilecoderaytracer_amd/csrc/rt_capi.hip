@@ -23,6 +23,11 @@ extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__re
                                             const RtRun *__restrict__ runs,
                                             const RtRun *__restrict__ shadow_runs, float *__restrict__ out);
 
+extern "C" __global__ void rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image,
+                                                  const RtRun *__restrict__ runs,
+                                                  const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
+                                                  unsigned long long *__restrict__ stats_out);
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -431,7 +436,7 @@ int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes) {
 }
 
 int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
-           float *d_out, hipStream_t stream) {
+           float *d_out, hipStream_t stream, unsigned long long *d_stats = nullptr) {
     if (!cam) return fail(RT_ERR_INVALID, "camera is NULL");
     if (W <= 0 || H <= 0) return fail(RT_ERR_INVALID, "W and H must be positive");
     if (x0 < 0 || x1 > W || x0 > x1) return fail(RT_ERR_INVALID, "need 0 <= x0 <= x1 <= W");
@@ -478,15 +483,24 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if (rc) return rc;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (d_stats)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel_stats),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     const int slot = s->ev_next;
     rc = drain_event(s, slot);            /* ring wrapped: account for the old launch first */
     if (rc) return rc;
     s->ev_next = (s->ev_next + 1) % kEventRing;
     HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
-    hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
-                       p, reinterpret_cast<const float4 *>(s->d_image),
-                       reinterpret_cast<const RtRun *>(s->d_runs),
-                       reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out);
+    if (d_stats)
+        hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
+                           stream, p, reinterpret_cast<const float4 *>(s->d_image),
+                           reinterpret_cast<const RtRun *>(s->d_runs),
+                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, d_stats);
+    else
+        hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
+                           p, reinterpret_cast<const float4 *>(s->d_image),
+                           reinterpret_cast<const RtRun *>(s->d_runs),
+                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
     s->ev[slot].pending = true;
@@ -586,6 +600,35 @@ int rt_render(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int 
         (void)hipEventDestroy(t1);
     }
     HIP_TRY(hipDeviceSynchronize());
+    return RT_OK;
+}
+
+int rt_render_stats(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
+                    float *out_rgb, uint64_t *stats, int n_stats) {
+    if (!s || !stats || n_stats < 0) return fail(RT_ERR_INVALID, "scene/stats is NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1) return fail(RT_ERR_INVALID, "need 0 <= x0 <= x1 <= W, W,H > 0");
+    const size_t bytes = (size_t)(x1 - x0) * (size_t)H * 3 * sizeof(float);
+    HIP_TRY(hipSetDevice(s->device));
+    if (bytes > s->d_fb_bytes) {
+        if (s->d_fb) { HIP_TRY(hipFree(s->d_fb)); s->d_fb = nullptr; s->d_fb_bytes = 0; }
+        HIP_TRY(hipMalloc(&s->d_fb, bytes));
+        s->d_fb_bytes = bytes;
+    }
+    unsigned long long *d_stats = nullptr;
+    HIP_TRY(hipMalloc(&d_stats, RT_STATS_COUNT * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d_stats, 0, RT_STATS_COUNT * sizeof(unsigned long long));
+    int rc = e == hipSuccess ? launch(s, cam, W, H, x0, x1, max_depth, static_cast<float *>(s->d_fb), nullptr, d_stats)
+                             : fail(RT_ERR_HIP, hipGetErrorString(e));
+    unsigned long long host[RT_STATS_COUNT] = {0};
+    if (rc == RT_OK) {
+        e = hipMemcpy(host, d_stats, sizeof(host), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_rgb && bytes) e = hipMemcpy(out_rgb, s->d_fb, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_stats);
+    if (rc) return rc;
+    for (int k = 0; k < n_stats; ++k) stats[k] = k < RT_STATS_COUNT ? host[k] : 0;
     return RT_OK;
 }
 

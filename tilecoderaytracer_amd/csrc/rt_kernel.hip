@@ -60,6 +60,30 @@ __device__ __forceinline__ V3 normalize3(const V3 v) {
  * run it anyway and discard the result. */
 __device__ __forceinline__ bool wave_any(const bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
+/* Work counters of the diagnostic ("counting") build, rt_render_stats().  In
+ * the production kernel kStats is false and every use folds away. */
+enum {
+    ST_NEAREST_RAYS = 0,    /* lanes: nearest-hit rays traced                              */
+    ST_SHADOW_RAYS,         /* lanes: shadow rays traced                                   */
+    ST_WAVE_NEAREST,        /* wavefronts: nearest_hit() calls                             */
+    ST_WAVE_SHADOW,         /* wavefronts: in_shade() calls                                */
+    ST_WAVE_SPHERE_TESTS,   /* wavefronts: sphere tests issued                             */
+    ST_WAVE_PLANE_TESTS,    /* wavefronts: plane tests issued                              */
+    ST_WAVE_BOX_TESTS,      /* wavefronts: cluster box tests issued                        */
+    ST_LANE_SPHERE_TESTS,   /* lanes: sphere tests the lane itself needed                  */
+    ST_COUNT
+};
+template <bool kStats> struct Stats { };
+template <> struct Stats<true> { unsigned int c[ST_COUNT]; };
+template <bool kStats> __device__ __forceinline__ void st_lane(Stats<kStats> &, int, bool) {}
+template <> __device__ __forceinline__ void st_lane<true>(Stats<true> &st, int k, bool cond) { st.c[k] += cond ? 1u : 0u; }
+template <bool kStats> __device__ __forceinline__ void st_wave(Stats<kStats> &, int) {}
+template <> __device__ __forceinline__ void st_wave<true>(Stats<true> &st, int k) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+    const int lane = (int)(threadIdx.x & 63u);
+    st.c[k] += (lane == __ffsll((long long)m) - 1) ? 1u : 0u;       /* first active lane counts for the wave */
+}
+
 /* SceneSphere::collision reduced to its distance, src/SceneSphere.cpp:50-116.
  * *hit is true when the reference would return a CollisionObject; *dist is
  * then the distance it reports (v - sqrt(d^2), negative for inside hits). */
@@ -184,11 +208,14 @@ __device__ __forceinline__ V3 approx_inverse(const V3 d) {
 
 /* getCollision, src/RayTracer.cpp:50-89: first strictly-smaller distance in
  * Scene index order wins; "infinity" is 65535. */
+template <bool kStats>
 __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__restrict__ runs,
                                             const float4 *lds, const V3 o, const V3 d,
-                                            float *best_out, int *best_idx_out) {
+                                            float *best_out, int *best_idx_out, Stats<kStats> &st) {
     float best = 65535.0f;
     int best_idx = -1;
+    st_lane(st, ST_NEAREST_RAYS, true);
+    st_wave(st, ST_WAVE_NEAREST);
     for (int r = 0; r < p.n_runs; ++r) {
         const RtRun run = runs[r];
         const float4 *g = lds + run.geom_off;
@@ -196,7 +223,7 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
 #pragma unroll 2
             for (int i = 0; i < run.count; ++i) {
                 bool hit; float t;
-                sphere_distance(g[i], o, d, &hit, &t);
+                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, true); sphere_distance(g[i], o, d, &hit, &t);
                 if (hit && t < best) { best = t; best_idx = run.first + i; }
             }
         } else if (run.kind == RT_KIND_SPHERE_CLUSTERED) {
@@ -207,19 +234,22 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
             for (int gi = 0; gi < run.count; ++gi) {
                 /* a hit that enters beyond the nearest distance so far cannot win */
                 const float4 g0 = g[gi * RT_CLUSTER_QUADS], g1 = g[gi * RT_CLUSTER_QUADS + 1];
+                st_wave(st, ST_WAVE_BOX_TESTS);
                 if (!wave_any(box_needed(g0, g1, o, inv, best))) continue;
                 const float4 *leaves = lds + __float_as_uint(g0.w);
                 const int n_leaves = (int)__float_as_uint(g1.w);
                 for (int c = 0; c < n_leaves; ++c) {
                     const float4 c0 = leaves[c * RT_CLUSTER_QUADS], c1 = leaves[c * RT_CLUSTER_QUADS + 1];
-                    if (!wave_any(box_needed(c0, c1, o, inv, best))) continue;
+                    st_wave(st, ST_WAVE_BOX_TESTS);
+                    const bool lane_needs = box_needed(c0, c1, o, inv, best);
+                    if (!wave_any(lane_needs)) continue;
                     const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
                     const int n = (int)(__float_as_uint(c0.w) >> 16);
                     const uint32_t *ids = cidx + __float_as_uint(c1.w);
 #pragma unroll 2
                     for (int i = 0; i < n; ++i) {
                         bool hit; float t;
-                        sphere_distance(m[i], o, d, &hit, &t);
+                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs); sphere_distance(m[i], o, d, &hit, &t);
                         if (wave_any(hit)) {
                             const int idx = (int)ids[i];
                             if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
@@ -230,14 +260,14 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
         } else if (run.kind == RT_KIND_INFINITE_PLANE) {
             for (int i = 0; i < run.count; ++i) {
                 bool hit; float t;
-                infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, best, &hit, &t);
+                st_wave(st, ST_WAVE_PLANE_TESTS); infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, best, &hit, &t);
                 if (hit && t < best) { best = t; best_idx = run.first + i; }
             }
         } else {
 #pragma unroll 2
             for (int i = 0; i < run.count; ++i) {
                 bool hit; float t;
-                finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, best, &hit, &t);
+                st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, best, &hit, &t);
                 if (hit && t < best) { best = t; best_idx = run.first + i; }
             }
         }
@@ -249,9 +279,13 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
 /* inShadeCollisionDetection, src/RayTracer.cpp:709-739: any non-light object
  * of the scan range with distance < dist_to_light blocks.  A boolean OR, so
  * the scan order is free; the wave stops when every lane is blocked. */
+template <bool kStats>
 __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restrict__ shadow_runs,
-                                         const float4 *lds, const V3 o, const V3 d, const float dist_to_light) {
+                                         const float4 *lds, const V3 o, const V3 d, const float dist_to_light,
+                                         Stats<kStats> &st) {
     bool blocked = false;
+    st_lane(st, ST_SHADOW_RAYS, true);
+    st_wave(st, ST_WAVE_SHADOW);
     for (int r = 0; r < p.n_shadow_runs; ++r) {
         if (!wave_any(!blocked)) break;
         const RtRun run = shadow_runs[r];
@@ -260,10 +294,10 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restr
             for (int i = 0; i < run.count; i += 2) {
                 if (!wave_any(!blocked)) break;
                 bool hit; float t;
-                sphere_distance(g[i], o, d, &hit, &t);
+                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, true); sphere_distance(g[i], o, d, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
                 if (i + 1 < run.count) {
-                    sphere_distance(g[i + 1], o, d, &hit, &t);
+                    st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, true); sphere_distance(g[i + 1], o, d, &hit, &t);
                     blocked = blocked || (hit && t < dist_to_light);
                 }
             }
@@ -272,18 +306,21 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restr
             for (int gi = 0; gi < run.count; ++gi) {
                 if (!wave_any(!blocked)) break;
                 const float4 g0 = g[gi * RT_CLUSTER_QUADS], g1 = g[gi * RT_CLUSTER_QUADS + 1];
+                st_wave(st, ST_WAVE_BOX_TESTS);
                 if (!wave_any(!blocked && box_needed(g0, g1, o, inv, dist_to_light))) continue;
                 const float4 *leaves = lds + __float_as_uint(g0.w);
                 const int n_leaves = (int)__float_as_uint(g1.w);
                 for (int c = 0; c < n_leaves; ++c) {
                     const float4 c0 = leaves[c * RT_CLUSTER_QUADS], c1 = leaves[c * RT_CLUSTER_QUADS + 1];
-                    if (!wave_any(!blocked && box_needed(c0, c1, o, inv, dist_to_light))) continue;
+                    st_wave(st, ST_WAVE_BOX_TESTS);
+                    const bool lane_needs = !blocked && box_needed(c0, c1, o, inv, dist_to_light);
+                    if (!wave_any(lane_needs)) continue;
                     const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
                     const int n = (int)(__float_as_uint(c0.w) >> 16);
 #pragma unroll 2
                     for (int i = 0; i < n; ++i) {
                         bool hit; float t;
-                        sphere_distance(m[i], o, d, &hit, &t);
+                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs); sphere_distance(m[i], o, d, &hit, &t);
                         blocked = blocked || (hit && t < dist_to_light);
                     }
                 }
@@ -291,17 +328,17 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restr
         } else if (run.kind == RT_KIND_INFINITE_PLANE) {
             for (int i = 0; i < run.count; ++i) {
                 bool hit; float t;
-                infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, dist_to_light, &hit, &t);
+                st_wave(st, ST_WAVE_PLANE_TESTS); infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
             }
         } else {
             for (int i = 0; i < run.count; i += 2) {
                 if (!wave_any(!blocked)) break;
                 bool hit; float t;
-                finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
+                st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
                 if (i + 1 < run.count) {
-                    finite_plane_distance(g + (i + 1) * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
+                    st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(g + (i + 1) * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
                     blocked = blocked || (hit && t < dist_to_light);
                 }
             }
@@ -331,10 +368,13 @@ __device__ __forceinline__ V3 entry_colour(const RtParams &p, const float4 *lds,
 
 } // namespace
 
-extern "C" __global__ void __launch_bounds__(256)
-rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
-                 const RtRun *__restrict__ shadow_runs, float *__restrict__ out) {
+template <bool kStats>
+__device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
+                                            const RtRun *__restrict__ runs, const RtRun *__restrict__ shadow_runs,
+                                            float *__restrict__ out, unsigned long long *__restrict__ stats_out) {
     extern __shared__ float4 lds[];
+    Stats<kStats> st;
+    if constexpr (kStats) for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
 
     /* stage the scene tables: global -> LDS, once per workgroup */
     for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
@@ -381,7 +421,7 @@ rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun
         if (alive) {
             float t;
             int idx;
-            nearest_hit(p, runs, lds, o, d, &t, &idx);
+            nearest_hit<kStats>(p, runs, lds, o, d, &t, &idx, st);
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
                 alive = false;
@@ -435,7 +475,7 @@ rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun
                         const V3 dir = sub3(xyz(l0), P);
                         const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                         const V3 light_ray = normalize3(dir);      /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
-                        if (!in_shade(p, shadow_runs, lds, P, light_ray, dist_to_light)) {
+                        if (!in_shade<kStats>(p, shadow_runs, lds, P, light_ray, dist_to_light, st)) {
                             const V3 light_color = xyz(l1);
                             /* cosineShade, :654-701 */
                             if (diffuse_factor > (float)0) {
@@ -505,4 +545,21 @@ rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun
         float *dst = out + ((size_t)(x - p.x0) * (size_t)p.H + (size_t)z) * 3;
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
     }
+    if constexpr (kStats)
+        for (int k = 0; k < ST_COUNT; ++k)
+            if (st.c[k]) atomicAdd(&stats_out[k], (unsigned long long)st.c[k]);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
+                 const RtRun *__restrict__ shadow_runs, float *__restrict__ out) {
+    render_body<false>(p, image, runs, shadow_runs, out, nullptr);
+}
+
+/* the counting build: same arithmetic and control flow plus work counters */
+extern "C" __global__ void __launch_bounds__(256)
+rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
+                       const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
+                       unsigned long long *__restrict__ stats_out) {
+    render_body<true>(p, image, runs, shadow_runs, out, stats_out);
 }

@@ -54,6 +54,18 @@ class Renderer:
         capi.check(self._lib.rt_render_device(self._scene, self._cam, W, H, x0, x1, max_depth,
                                               C.c_void_p(device_ptr), C.c_void_p(stream)))
 
+    STAT_NAMES = ("nearest_rays", "shadow_rays", "wave_nearest_scans", "wave_shadow_scans",
+                  "wave_sphere_tests", "wave_plane_tests", "wave_box_tests", "lane_sphere_tests")
+
+    def render_stats(self, W, H, max_depth, x0=0, x1=None):
+        """Counting build: returns (image, {counter: value})."""
+        x1 = W if x1 is None else x1
+        out = np.empty((max(x1 - x0, 0), H, 3), dtype=np.float32)
+        st = (C.c_uint64 * 8)()
+        capi.check(self._lib.rt_render_stats(self._scene, self._cam, W, H, x0, x1, max_depth,
+                                             out.ctypes.data, st, 8))
+        return out, dict(zip(self.STAT_NAMES, [int(v) for v in st]))
+
     def timing(self):
         t = capi.RtTiming()
         capi.check(self._lib.rt_get_timing(self._scene, C.byref(t)))
