@@ -21,11 +21,13 @@
 
 extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__restrict__ image,
                                             const RtRun *__restrict__ runs,
-                                            const RtRun *__restrict__ shadow_runs, float *__restrict__ out);
+                                            const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
+                                            unsigned int *__restrict__ tile_counter);
 
 extern "C" __global__ void rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image,
                                                   const RtRun *__restrict__ runs,
                                                   const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
+                                                  unsigned int *__restrict__ tile_counter,
                                                   unsigned long long *__restrict__ stats_out);
 
 namespace {
@@ -76,6 +78,9 @@ struct rt_scene {
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
     int n_clusters = 0;
+    /* tile queue heads, one per in-flight launch (same ring as the events) */
+    unsigned int *d_counters = nullptr;
+    int n_cus = 0;
     /* timing */
     EventPair ev[kEventRing];
     int ev_next = 0;
@@ -468,19 +473,35 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.tiles_z = (int)tiles_z;
     p.n_tiles = (int)n_tiles;
     const int waves_per_block = block / 64;
-    const long long blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
+    const long long blocks_all = (n_tiles + waves_per_block - 1) / waves_per_block;
 
     s->launch.block_threads = block;
     s->launch.lds_bytes = lds_bytes;
     s->launch.scene_lds_bytes = s->base.image_quads * 16;
-    s->launch.grid_blocks = (int)blocks;
     s->launch.tile_x = tile_x;
     s->launch.tile_z = tile_z;
-    if (blocks == 0) return RT_OK;
+    s->launch.grid_blocks = 0;
+    if (blocks_all == 0) return RT_OK;
 
     HIP_TRY(hipSetDevice(s->device));
     rc = ensure_events(s);
     if (rc) return rc;
+    /* persistent grid: as many workgroups as the chip holds at once (by the
+     * occupancy query; a larger grid would also be correct, its surplus
+     * workgroups simply find the queue empty), never more than there are tiles */
+    if (!s->d_counters) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters), kEventRing * sizeof(unsigned int)));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, reinterpret_cast<const void *>(d_stats ? (const void *)rt_render_kernel_stats : (const void *)rt_render_kernel),
+        block, (size_t)lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    const long long blocks = std::min(blocks_all, (long long)per_cu * (long long)s->n_cus);
+    s->launch.grid_blocks = (int)blocks;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (d_stats)
@@ -490,17 +511,19 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     rc = drain_event(s, slot);            /* ring wrapped: account for the old launch first */
     if (rc) return rc;
     s->ev_next = (s->ev_next + 1) % kEventRing;
+    unsigned int *counter = s->d_counters + slot;
+    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
     if (d_stats)
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
                            stream, p, reinterpret_cast<const float4 *>(s->d_image),
                            reinterpret_cast<const RtRun *>(s->d_runs),
-                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, d_stats);
+                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter, d_stats);
     else
         hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
                            reinterpret_cast<const RtRun *>(s->d_runs),
-                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out);
+                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
     s->ev[slot].pending = true;
@@ -550,13 +573,14 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
 
 int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
-    if (s->d_image || s->d_fb || s->ev_ready) (void)hipSetDevice(s->device);
+    if (s->d_image || s->d_fb || s->d_counters || s->ev_ready) (void)hipSetDevice(s->device);
     if (s->ev_ready)
         for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].stop); }
     if (s->d_image) (void)hipFree(s->d_image);
     if (s->d_runs) (void)hipFree(s->d_runs);
     if (s->d_shadow_runs) (void)hipFree(s->d_shadow_runs);
     if (s->d_fb) (void)hipFree(s->d_fb);
+    if (s->d_counters) (void)hipFree(s->d_counters);
     delete s;
     return RT_OK;
 }
@@ -604,7 +628,7 @@ int rt_render(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int 
 }
 
 int rt_render_stats(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
-                    float *out_rgb, uint64_t *stats, int n_stats) {
+                    float *out_rgb, uint64_t *stats, int n_stats, uint64_t *wave_cycles, int n_wave_cycles) {
     if (!s || !stats || n_stats < 0) return fail(RT_ERR_INVALID, "scene/stats is NULL");
     std::lock_guard<std::mutex> lock(s->mu);
     if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1) return fail(RT_ERR_INVALID, "need 0 <= x0 <= x1 <= W, W,H > 0");
@@ -615,15 +639,23 @@ int rt_render_stats(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0
         HIP_TRY(hipMalloc(&s->d_fb, bytes));
         s->d_fb_bytes = bytes;
     }
+    /* counters, then one cycle count per wavefront tile */
+    const int tile_z = 1 << s->tile_z_log2, tile_x = 64 >> s->tile_z_log2;
+    const size_t n_tiles = (size_t)((H + tile_z - 1) / tile_z) * (size_t)((x1 - x0 + tile_x - 1) / tile_x);
+    const size_t words = RT_STATS_COUNT + n_tiles * RT_TILE_STATS;
     unsigned long long *d_stats = nullptr;
-    HIP_TRY(hipMalloc(&d_stats, RT_STATS_COUNT * sizeof(unsigned long long)));
-    hipError_t e = hipMemset(d_stats, 0, RT_STATS_COUNT * sizeof(unsigned long long));
+    HIP_TRY(hipMalloc(&d_stats, words * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d_stats, 0, words * sizeof(unsigned long long));
     int rc = e == hipSuccess ? launch(s, cam, W, H, x0, x1, max_depth, static_cast<float *>(s->d_fb), nullptr, d_stats)
                              : fail(RT_ERR_HIP, hipGetErrorString(e));
     unsigned long long host[RT_STATS_COUNT] = {0};
     if (rc == RT_OK) {
         e = hipMemcpy(host, d_stats, sizeof(host), hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_rgb && bytes) e = hipMemcpy(out_rgb, s->d_fb, bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && wave_cycles && n_wave_cycles > 0)
+            e = hipMemcpy(wave_cycles, d_stats + RT_STATS_COUNT,
+                          std::min((size_t)n_wave_cycles, n_tiles * RT_TILE_STATS) * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RT_ERR_HIP, hipGetErrorString(e));
     }
     (void)hipFree(d_stats);

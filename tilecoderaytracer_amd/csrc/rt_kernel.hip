@@ -371,10 +371,11 @@ __device__ __forceinline__ V3 entry_colour(const RtParams &p, const float4 *lds,
 template <bool kStats>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             const RtRun *__restrict__ runs, const RtRun *__restrict__ shadow_runs,
-                                            float *__restrict__ out, unsigned long long *__restrict__ stats_out) {
+                                            float *__restrict__ out, unsigned int *__restrict__ tile_counter,
+                                            unsigned long long *__restrict__ stats_out) {
     extern __shared__ float4 lds[];
     Stats<kStats> st;
-    if constexpr (kStats) for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
+    unsigned long long t_start = 0ull, t_start_real = 0ull;
 
     /* stage the scene tables: global -> LDS, once per workgroup */
     for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
@@ -383,16 +384,33 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     float4 *stack = lds + p.image_quads;          /* [level][threadIdx.x] */
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
 
+    /* Self-scheduling (the reference's strategy 2, src/RayTracer.cpp:956-992:
+     * a shared queue of pixels; here a queue of wavefront tiles).  The grid is
+     * only as large as the chip can hold; every WAVEFRONT pulls its next tile
+     * from one device-wide counter until the tiles run out, so expensive tiles
+     * (the horizon, mirror balls) cannot pile up on one XCD the way a static
+     * block -> tile map lets them.  All lanes are active here; every wavefront
+     * reaches the exit test, so the grid always drains. */
+    const int lane = threadIdx.x & 63;
+    const int tz = 1 << p.tile_z_log2;
+  for (;;) {
+    int wave = 0;
+    if (lane == 0) wave = (int)atomicAdd(tile_counter, 1u);
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    if (wave >= p.n_tiles) break;
+    if constexpr (kStats) {
+        for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
+        t_start = __builtin_amdgcn_s_memtime();
+        t_start_real = __builtin_amdgcn_s_memrealtime();
+    }
+
     /* pixel of this lane: wavefront tiles are tile_x columns by tile_z rows;
      * consecutive lanes walk z, the contiguous axis of pixels[x][z] */
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int tile_col = wave / p.tiles_z;
     const int tile_row = wave - tile_col * p.tiles_z;
-    const int tz = 1 << p.tile_z_log2;
     const int x = p.x0 + tile_col * (64 >> p.tile_z_log2) + (lane >> p.tile_z_log2);
     const int z = tile_row * tz + (lane & (tz - 1));
-    const bool inside = (wave < p.n_tiles) && (x < p.x1) && (z < p.H);
+    const bool inside = (x < p.x1) && (z < p.H);
 
     /* Camera::createEyeRay, src/Camera.cpp:71-84, with dx = (float)x / W,
      * dz = (float)z / H from the pixel loop, src/RayTracer.cpp:916-918 */
@@ -545,21 +563,37 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         float *dst = out + ((size_t)(x - p.x0) * (size_t)p.H + (size_t)z) * 3;
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
     }
-    if constexpr (kStats)
+    if constexpr (kStats) {
         for (int k = 0; k < ST_COUNT; ++k)
             if (st.c[k]) atomicAdd(&stats_out[k], (unsigned long long)st.c[k]);
+        /* per wavefront tile: shader cycles spent on it, then its wave-level counters */
+        {
+            unsigned long long *rec = stats_out + ST_COUNT + (size_t)wave * RT_TILE_STATS;
+            if (lane == 0) {
+                rec[0] = __builtin_amdgcn_s_memtime() - t_start;
+                rec[4] = t_start_real;                               /* 100 MHz constant clock */
+                rec[5] = __builtin_amdgcn_s_memrealtime();
+            }
+            if (st.c[ST_WAVE_SPHERE_TESTS]) atomicAdd(&rec[1], (unsigned long long)st.c[ST_WAVE_SPHERE_TESTS]);
+            if (st.c[ST_WAVE_BOX_TESTS]) atomicAdd(&rec[2], (unsigned long long)st.c[ST_WAVE_BOX_TESTS]);
+            if (st.c[ST_WAVE_NEAREST] + st.c[ST_WAVE_SHADOW])
+                atomicAdd(&rec[3], (unsigned long long)(st.c[ST_WAVE_NEAREST] + st.c[ST_WAVE_SHADOW]));
+        }
+    }
+  }   /* next tile */
 }
 
 extern "C" __global__ void __launch_bounds__(256)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
-                 const RtRun *__restrict__ shadow_runs, float *__restrict__ out) {
-    render_body<false>(p, image, runs, shadow_runs, out, nullptr);
+                 const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
+                 unsigned int *__restrict__ tile_counter) {
+    render_body<false>(p, image, runs, shadow_runs, out, tile_counter, nullptr);
 }
 
 /* the counting build: same arithmetic and control flow plus work counters */
 extern "C" __global__ void __launch_bounds__(256)
 rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
                        const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
-                       unsigned long long *__restrict__ stats_out) {
-    render_body<true>(p, image, runs, shadow_runs, out, stats_out);
+                       unsigned int *__restrict__ tile_counter, unsigned long long *__restrict__ stats_out) {
+    render_body<true>(p, image, runs, shadow_runs, out, tile_counter, stats_out);
 }

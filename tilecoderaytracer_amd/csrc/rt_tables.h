@@ -66,6 +66,8 @@
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
 #define RT_MAX_LDS_BYTES  (160 * 1024)
 
+#define RT_TILE_STATS 6          /* counting build: words per wavefront tile {cycles, sphere tests, box tests, scans, start, end (100 MHz clock)} */
+
 #define RT_STACK_ENTRY_BYTES 16   /* {local.rgb, bits(object index | texsel << 16)} per bounce level per lane */
 
 typedef struct RtRun {

@@ -57,14 +57,21 @@ class Renderer:
     STAT_NAMES = ("nearest_rays", "shadow_rays", "wave_nearest_scans", "wave_shadow_scans",
                   "wave_sphere_tests", "wave_plane_tests", "wave_box_tests", "lane_sphere_tests")
 
-    def render_stats(self, W, H, max_depth, x0=0, x1=None):
-        """Counting build: returns (image, {counter: value})."""
+    def render_stats(self, W, H, max_depth, x0=0, x1=None, wave_cycles=False):
+        """Counting build: returns (image, {counter: value}[, per wavefront tile (tiles_x, tiles_z, 6) = cycles, sphere tests, box tests, scans, start, end (100 MHz)])."""
         x1 = W if x1 is None else x1
         out = np.empty((max(x1 - x0, 0), H, 3), dtype=np.float32)
         st = (C.c_uint64 * 8)()
+        li = self.launch_info()
+        tz = li.tile_z or 4
+        tx = 64 // tz
+        tiles = ((x1 - x0 + tx - 1) // tx, (H + tz - 1) // tz)
+        cyc = np.zeros(tiles + (6,), dtype=np.uint64)
         capi.check(self._lib.rt_render_stats(self._scene, self._cam, W, H, x0, x1, max_depth,
-                                             out.ctypes.data, st, 8))
-        return out, dict(zip(self.STAT_NAMES, [int(v) for v in st]))
+                                             out.ctypes.data, st, 8,
+                                             cyc.ctypes.data if wave_cycles else None, cyc.size if wave_cycles else 0))
+        stats = dict(zip(self.STAT_NAMES, [int(v) for v in st]))
+        return (out, stats, cyc) if wave_cycles else (out, stats)
 
     def timing(self):
         t = capi.RtTiming()
