@@ -144,8 +144,8 @@ int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W,
  *   4 sphere tests issued (wavefronts) 5 plane tests issued (wavefronts)
  *   6 cluster box tests issued (wavefronts)
  *   7 sphere tests the lane itself needed (lanes)
- * wave_cycles (may be NULL) receives, per wavefront tile in tile-column-major
- * order (tile = tile_col * tiles_z + tile_row), six words {shader cycles the
+ * wave_cycles (may be NULL) receives, per wavefront tile in row-major order
+ * (tile = tile_row * tiles_x + tile_col), six words {shader cycles the
  * wavefront was resident, sphere tests it issued, box tests it issued, scans
  * it ran, start and end time on the 100 MHz constant clock}, up to
  * n_wave_cycles words.  out_rgb may be NULL.  The reference has no

@@ -13,7 +13,7 @@ t = t.astype(np.float64)
 for k, nm in enumerate(["cycles", "sphere tests", "box tests", "scans"]):
     c = t[..., k]
     print(f"{nm:13s} sum {c.sum():.3e} mean {c.mean():9.0f} median {np.median(c):9.0f} p99 {np.percentile(c, 99):9.0f} max {c.max():9.0f}")
-    rows = c.mean(axis=0).reshape(32, -1).mean(axis=1)
+    rows = c.mean(axis=1).reshape(32, -1).mean(axis=1)
     print("   per tile-row band (bottom->top):", " ".join(f"{v:.0f}" for v in rows))
 # schedule: how many wavefronts are resident over time
 t0 = t[..., 4].min()
@@ -28,5 +28,5 @@ for a, b in zip(edges[:-1], edges[1:]):
     started = np.sum((start >= a) & (start < b))
     print(f"   t={mid:8.0f} us resident waves {resident:6d}  started in bin {started:6d}")
 late = np.argsort(end)[-8:]
-tz = t.shape[1]
-print("last finishers (tile_col, tile_row, start us, dur us):", [(int(i // tz), int(i % tz), int(start[i]), int(end[i]-start[i])) for i in late])
+tx = t.shape[1]
+print("last finishers (tile_row, tile_col, start us, dur us):", [(int(i // tx), int(i % tx), int(start[i]), int(end[i]-start[i])) for i in late])

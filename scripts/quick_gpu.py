@@ -9,7 +9,7 @@ if "only" in opts:
     cases = [c for c in cases if c[0] in opts["only"].split(",")]
 for name, S, d in cases:
     r = Renderer(HostScene.named(name))
-    for k in ("tile_z", "block_threads", "cluster_leaf", "cluster_group"):
+    for k in ("tile_z", "block_threads", "cluster_leaf", "cluster_group", "grid_mult", "tiles_per_grab"):
         if k in opts:
             r.set_option(k, int(opts[k]))
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
@@ -22,4 +22,4 @@ for name, S, d in cases:
     torch.cuda.synchronize()
     tm = r.timing(); li = r.launch_info()
     ms = tm.sum_kernel_ms / tm.launches
-    print(f"{name:16s} {S}x{S} d{d}: {ms:9.3f} ms  {S*S/ms/1e3:9.1f} Mrays/s  block {li.block_threads} lds {li.lds_bytes} tile {li.tile_x}x{li.tile_z}", flush=True)
+    print(f"{name:16s} {S}x{S} d{d}: {ms:9.3f} ms  {S*S/ms/1e3:9.1f} Mrays/s  block {li.block_threads} lds {li.lds_bytes} tile {li.tile_x}x{li.tile_z} grid {li.grid_blocks}", flush=True)

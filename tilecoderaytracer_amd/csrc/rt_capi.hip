@@ -75,6 +75,8 @@ struct rt_scene {
     /* options */
     int tile_z_log2 = 2;          /* 16 columns x 4 rows per wavefront (measured best on MI355X: wide tiles diverge least) */
     int block_threads_opt = 0;    /* 0 = auto */
+    int tiles_per_grab_opt = 0;   /* 0 = auto */
+    int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
     int n_clusters = 0;
@@ -471,6 +473,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     const long long n_tiles = tiles_z * tiles_x;
     if (n_tiles > 0x7fffffffLL) return fail(RT_ERR_INVALID, "too many tiles");
     p.tiles_z = (int)tiles_z;
+    p.tiles_x = (int)tiles_x;
     p.n_tiles = (int)n_tiles;
     const int waves_per_block = block / 64;
     const long long blocks_all = (n_tiles + waves_per_block - 1) / waves_per_block;
@@ -500,13 +503,28 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         &per_cu, reinterpret_cast<const void *>(d_stats ? (const void *)rt_render_kernel_stats : (const void *)rt_render_kernel),
         block, (size_t)lds_bytes));
     if (per_cu < 1) per_cu = 1;
-    const long long blocks = std::min(blocks_all, (long long)per_cu * (long long)s->n_cus);
+    const long long blocks = s->grid_mult > 0
+        ? std::min(blocks_all, (long long)per_cu * (long long)s->n_cus * (long long)s->grid_mult)
+        : blocks_all;
     s->launch.grid_blocks = (int)blocks;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (d_stats)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel_stats),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    /* Tiles per queue pop.  One counter word saturates near 88 pops/us
+     * (MI355X_MICROARCH.md, "dequeue"); tiles of a small scene are cheap enough
+     * to get there (built-in scene: ~110 tiles/us), so they are handed out in
+     * pairs; heavy scenes pop single tiles for the finest balance.  Always keep
+     * at least ~16 pops per resident wavefront. */
+    {
+        const long long waves = blocks * waves_per_block;
+        long long per = s->objects.size() <= 128 ? 2 : 1;
+        per = std::max(1LL, std::min(per, n_tiles / (waves * 16)));
+        if (s->tiles_per_grab_opt > 0) per = s->tiles_per_grab_opt;
+        p.tiles_per_grab = (int)per;
+        p.n_grabs = (int)((n_tiles + per - 1) / per);
+    }
     const int slot = s->ev_next;
     rc = drain_event(s, slot);            /* ring wrapped: account for the old launch first */
     if (rc) return rc;
@@ -712,6 +730,16 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         if (value != 0 && (value < 64 || value > 256 || (value % 64) != 0))
             return fail(RT_ERR_INVALID, "block_threads must be 0 (auto), 64, 128, 192 or 256");
         s->block_threads_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "tiles_per_grab")) {
+        if (value < 0 || value > 1024) return fail(RT_ERR_INVALID, "tiles_per_grab must be in [0, 1024]");
+        s->tiles_per_grab_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "grid_mult")) {
+        if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "grid_mult must be in [0, 64]");
+        s->grid_mult = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "cluster_leaf") || !std::strcmp(key, "cluster_group")) {

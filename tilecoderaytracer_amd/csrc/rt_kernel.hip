@@ -393,10 +393,19 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * reaches the exit test, so the grid always drains. */
     const int lane = threadIdx.x & 63;
     const int tz = 1 << p.tile_z_log2;
+    /* One atomic hands out `tiles_per_grab` tiles (a single counter word
+     * saturates near 88 dequeues/us, which cheap tiles would exceed).  The
+     * tiles of one grab are n_grabs apart, not adjacent, so expensive
+     * neighbourhoods are spread over many wavefronts. */
+    int next_grab = 0;
+    if (lane == 0) next_grab = (int)atomicAdd(tile_counter, 1u);
   for (;;) {
-    int wave = 0;
-    if (lane == 0) wave = (int)atomicAdd(tile_counter, 1u);
-    wave = __builtin_amdgcn_readfirstlane(wave);
+    const int grab = __builtin_amdgcn_readfirstlane(next_grab);
+    if (grab >= p.n_grabs) break;
+    /* ask for the following grab now; the answer is only needed after this one is rendered */
+    if (lane == 0) next_grab = (int)atomicAdd(tile_counter, 1u);
+   for (int part = 0; part < p.tiles_per_grab; ++part) {
+    const int wave = part * p.n_grabs + grab;
     if (wave >= p.n_tiles) break;
     if constexpr (kStats) {
         for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
@@ -406,8 +415,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 
     /* pixel of this lane: wavefront tiles are tile_x columns by tile_z rows;
      * consecutive lanes walk z, the contiguous axis of pixels[x][z] */
-    const int tile_col = wave / p.tiles_z;
-    const int tile_row = wave - tile_col * p.tiles_z;
+    /* tiles are numbered row by row (z outer): the tiles of one grab, n_grabs
+     * apart, then lie in different rows of the image */
+    const int tile_row = wave / p.tiles_x;
+    const int tile_col = wave - tile_row * p.tiles_x;
     const int x = p.x0 + tile_col * (64 >> p.tile_z_log2) + (lane >> p.tile_z_log2);
     const int z = tile_row * tz + (lane & (tz - 1));
     const bool inside = (x < p.x1) && (z < p.H);
@@ -580,10 +591,11 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 atomicAdd(&rec[3], (unsigned long long)(st.c[ST_WAVE_NEAREST] + st.c[ST_WAVE_SHADOW]));
         }
     }
-  }   /* next tile */
+   }  /* next tile of this grab */
+  }   /* next grab */
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, 6)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
                  const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
                  unsigned int *__restrict__ tile_counter) {

@@ -90,7 +90,10 @@ typedef struct RtParams {
     /* tiling: a wavefront renders tile_x x tile_z pixels, tile_x * tile_z == 64 */
     int32_t tile_z_log2;
     int32_t tiles_z;                     /* wavefront tiles along z */
+    int32_t tiles_x;                     /* wavefront tiles along x */
     int32_t n_tiles;                     /* total wavefront tiles   */
+    int32_t tiles_per_grab;              /* tiles handed out per queue pop               */
+    int32_t n_grabs;                     /* ceil(n_tiles / tiles_per_grab): queue length */
 } RtParams;
 
 #endif /* RT_TABLES_H_ */

@@ -58,14 +58,14 @@ class Renderer:
                   "wave_sphere_tests", "wave_plane_tests", "wave_box_tests", "lane_sphere_tests")
 
     def render_stats(self, W, H, max_depth, x0=0, x1=None, wave_cycles=False):
-        """Counting build: returns (image, {counter: value}[, per wavefront tile (tiles_x, tiles_z, 6) = cycles, sphere tests, box tests, scans, start, end (100 MHz)])."""
+        """Counting build: returns (image, {counter: value}[, per wavefront tile (tiles_z, tiles_x, 6) = cycles, sphere tests, box tests, scans, start, end (100 MHz)])."""
         x1 = W if x1 is None else x1
         out = np.empty((max(x1 - x0, 0), H, 3), dtype=np.float32)
         st = (C.c_uint64 * 8)()
         li = self.launch_info()
         tz = li.tile_z or 4
         tx = 64 // tz
-        tiles = ((x1 - x0 + tx - 1) // tx, (H + tz - 1) // tz)
+        tiles = ((H + tz - 1) // tz, (x1 - x0 + tx - 1) // tx)      # (tile rows, tile columns), row-major
         cyc = np.zeros(tiles + (6,), dtype=np.uint64)
         capi.check(self._lib.rt_render_stats(self._scene, self._cam, W, H, x0, x1, max_depth,
                                              out.ctypes.data, st, 8,
