@@ -160,12 +160,30 @@ def test_partial_shadow_range(oracle):
         assert_same(Renderer(host).render(64, 48, 4), orc.render(64, 48, 4), f"indices {rank}/{size}")
 
 
-def test_depth_too_deep_for_lds_is_an_error_not_a_fallback():
+def test_absurd_depth_is_an_error_not_a_fallback():
     from tilecoderaytracer_amd import RtError, capi
     r = Renderer(HostScene.builtin())
     with pytest.raises(RtError) as e:
-        r.render(8, 8, 100000)
+        r.render(8, 8, 2000000000)          # the bounce stack would need > 8 GB of HBM
     assert e.value.code == capi.RT_ERR_CAPACITY
+
+
+def test_facing_mirrors_depth_400(oracle):
+    """Two perfect mirrors facing each other: every level of the bounce stack is used."""
+    host, orc = HostScene.empty(), oracle.OracleScene()
+    for s in (host, orc):
+        i = s.add_sphere((3.0, 5.0, 8.0), 0.15)
+        s.set_light(i)
+        a = s.add_finite_plane_axes((-4.0, 9.0, -1.0), (0.0, -1.0, 0.0), (1.0, 0.0, 0.0), 8.0, 8.0)
+        b = s.add_finite_plane_axes((4.0, -3.0, -1.0), (0.0, 1.0, 0.0), (-1.0, 0.0, 0.0), 8.0, 8.0)
+        for m in (a, b):
+            s.set_reflective(m, 1.0)
+            s.set_diffuse(m, 0.0)
+        k = s.add_sphere((0.5, 3.0, 2.0), 0.7)
+        s.set_color(k, (1, 0, 0))
+        s.set_object_indices(0, 1)
+        s.camera_two_mirrors()
+    assert_same(Renderer(host).render(48, 40, 400), orc.render(48, 40, 400), "facing mirrors d400")
 
 
 # ------------------------------------------- full-size (BASELINE.json sizes)

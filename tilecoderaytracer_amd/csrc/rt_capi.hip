@@ -22,12 +22,14 @@
 extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__restrict__ image,
                                             const RtRun *__restrict__ runs,
                                             const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
-                                            unsigned int *__restrict__ tile_counter);
+                                            unsigned int *__restrict__ tile_counter,
+                                            float4 *__restrict__ bounce_stack);
 
 extern "C" __global__ void rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image,
                                                   const RtRun *__restrict__ runs,
                                                   const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
                                                   unsigned int *__restrict__ tile_counter,
+                                                  float4 *__restrict__ bounce_stack,
                                                   unsigned long long *__restrict__ stats_out);
 
 namespace {
@@ -82,6 +84,11 @@ struct rt_scene {
     int n_clusters = 0;
     /* tile queue heads, one per in-flight launch (same ring as the events) */
     unsigned int *d_counters = nullptr;
+    /* bounce stack in HBM: grid_blocks x (max_depth + 1) x block_threads entries of 16 B */
+    void *d_stack = nullptr;
+    size_t d_stack_bytes = 0;
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
     int n_cus = 0;
     /* timing */
     EventPair ev[kEventRing];
@@ -335,7 +342,7 @@ int pack_scene(rt_scene *s) {
     b.n_shadow_runs = (int)s->shadow_runs.size();
     b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
     for (int c = 0; c < 3; ++c) b.null_color[c] = s->null_color[c];
-    if ((size_t)b.image_quads * 16 + 64 * RT_STACK_ENTRY_BYTES > RT_MAX_LDS_BYTES)
+    if ((size_t)b.image_quads * 16 > RT_MAX_LDS_BYTES)
         return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
     return RT_OK;
 }
@@ -418,28 +425,15 @@ int drain_event(rt_scene *s, int i) {
     return RT_OK;
 }
 
-/* choose the workgroup size so tables + bounce stack fit in LDS */
-int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes) {
+/* workgroup size: the scene tables are the only LDS user (the bounce stack
+ * lives in HBM), so a bigger workgroup shares one staged copy among more
+ * wavefronts */
+int choose_block(const rt_scene *s, int *block, int *lds_bytes) {
     const size_t scene_bytes = (size_t)s->base.image_quads * 16;
-    const size_t per_thread = (size_t)RT_STACK_ENTRY_BYTES * (size_t)(max_depth + 1);
-    const int candidates[3] = {256, 128, 64};
-    if (s->block_threads_opt) {
-        const size_t need = scene_bytes + per_thread * (size_t)s->block_threads_opt;
-        if (need > RT_MAX_LDS_BYTES)
-            return fail(RT_ERR_CAPACITY, "block_threads option: tables + bounce stack exceed 160 KiB LDS");
-        *block = s->block_threads_opt; *lds_bytes = (int)need;
-        return RT_OK;
-    }
-    /* prefer the largest workgroup that still leaves room for two per CU,
-     * else the largest that fits at all */
-    for (int pass = 0; pass < 2; ++pass) {
-        const size_t limit = pass == 0 ? RT_MAX_LDS_BYTES / 2 : RT_MAX_LDS_BYTES;
-        for (int c : candidates) {
-            const size_t need = scene_bytes + per_thread * (size_t)c;
-            if (need <= limit) { *block = c; *lds_bytes = (int)need; return RT_OK; }
-        }
-    }
-    return fail(RT_ERR_CAPACITY, "max_depth too large: scene tables + bounce stack exceed 160 KiB LDS");
+    if (scene_bytes > RT_MAX_LDS_BYTES) return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
+    *block = s->block_threads_opt ? s->block_threads_opt : 256;
+    *lds_bytes = (int)scene_bytes;
+    return RT_OK;
 }
 
 int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
@@ -453,7 +447,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         return fail(RT_ERR_INVALID, "strip too large");
 
     int block = 0, lds_bytes = 0;
-    int rc = choose_block(s, max_depth, &block, &lds_bytes);
+    int rc = choose_block(s, &block, &lds_bytes);
     if (rc) return rc;
 
     RtParams p = s->base;
@@ -512,6 +506,24 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if (d_stats)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel_stats),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    /* bounce stack: one slice per workgroup of the persistent grid */
+    {
+        const double need_d = (double)blocks * (double)block * (double)(max_depth + 1) * RT_STACK_ENTRY_BYTES;
+        if (need_d > 8.0e9)
+            return fail(RT_ERR_CAPACITY, "max_depth too large: the bounce stack would exceed 8 GB of HBM");
+        const size_t need = (size_t)need_d;
+        /* the stack (and nothing else) is shared by successive launches of this handle:
+         * launches must be stream-ordered, so fence when the caller switches streams */
+        if (s->has_last_stream && s->last_stream != stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
+        s->last_stream = stream;
+        s->has_last_stream = true;
+        if (need > s->d_stack_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (s->d_stack) { HIP_TRY(hipFree(s->d_stack)); s->d_stack = nullptr; s->d_stack_bytes = 0; }
+            HIP_TRY(hipMalloc(&s->d_stack, need));
+            s->d_stack_bytes = need;
+        }
+    }
     /* Tiles per queue pop.  One counter word saturates near 88 pops/us
      * (MI355X_MICROARCH.md, "dequeue"); tiles of a small scene are cheap enough
      * to get there (built-in scene: ~110 tiles/us), so they are handed out in
@@ -536,12 +548,14 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
                            stream, p, reinterpret_cast<const float4 *>(s->d_image),
                            reinterpret_cast<const RtRun *>(s->d_runs),
-                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter, d_stats);
+                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter,
+                           reinterpret_cast<float4 *>(s->d_stack), d_stats);
     else
         hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
                            reinterpret_cast<const RtRun *>(s->d_runs),
-                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter);
+                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter,
+                           reinterpret_cast<float4 *>(s->d_stack));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
     s->ev[slot].pending = true;
@@ -599,6 +613,7 @@ int rt_scene_destroy(rt_scene *s) {
     if (s->d_shadow_runs) (void)hipFree(s->d_shadow_runs);
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_stack) (void)hipFree(s->d_stack);
     delete s;
     return RT_OK;
 }
@@ -727,8 +742,8 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
     if (!std::strcmp(key, "block_threads")) {
-        if (value != 0 && (value < 64 || value > 256 || (value % 64) != 0))
-            return fail(RT_ERR_INVALID, "block_threads must be 0 (auto), 64, 128, 192 or 256");
+        if (value != 0 && (value < 64 || value > 512 || (value % 64) != 0))
+            return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or a multiple of 64 up to 512");
         s->block_threads_opt = value;
         return RT_OK;
     }

@@ -16,7 +16,7 @@
  *    same operations in the same order.
  *  - The recursion `final_k = local_k + (rf_k * C_{k+1}) * oc_k`
  *    (src/RayTracer.cpp:601) is flattened: a forward loop over bounce levels
- *    pushes {local_k, object} on a per-lane stack in LDS, a backward loop
+ *    pushes {local_k, object} on a per-lane stack (16 B per level), a backward loop
  *    combines inside-out, so the association order is the reference's.
  *  - The object list is walked as runs of one primitive kind (rt_tables.h) in
  *    Scene index order; the loop counters are wave-uniform, the tables are read
@@ -372,6 +372,7 @@ template <bool kStats>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             const RtRun *__restrict__ runs, const RtRun *__restrict__ shadow_runs,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
+                                            float4 *__restrict__ bounce_stack,
                                             unsigned long long *__restrict__ stats_out) {
     extern __shared__ float4 lds[];
     Stats<kStats> st;
@@ -381,7 +382,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
     __syncthreads();
 
-    float4 *stack = lds + p.image_quads;          /* [level][threadIdx.x] */
+    /* this workgroup's slice of the bounce stack in HBM: [level][threadIdx.x],
+     * one 16-byte entry per reflective level per lane, written and read
+     * coalesced (LDS is left to the scene tables: occupancy) */
+    float4 *stack = bounce_stack + (size_t)blockIdx.x * (size_t)(p.max_depth + 1) * blockDim.x;
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
 
     /* Self-scheduling (the reference's strategy 2, src/RayTracer.cpp:956-992:
@@ -595,17 +599,18 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
   }   /* next grab */
 }
 
-extern "C" __global__ void __launch_bounds__(256, 6)
+extern "C" __global__ void __launch_bounds__(512)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
                  const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
-                 unsigned int *__restrict__ tile_counter) {
-    render_body<false>(p, image, runs, shadow_runs, out, tile_counter, nullptr);
+                 unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack) {
+    render_body<false>(p, image, runs, shadow_runs, out, tile_counter, bounce_stack, nullptr);
 }
 
 /* the counting build: same arithmetic and control flow plus work counters */
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(512)
 rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
                        const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
-                       unsigned int *__restrict__ tile_counter, unsigned long long *__restrict__ stats_out) {
-    render_body<true>(p, image, runs, shadow_runs, out, tile_counter, stats_out);
+                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                       unsigned long long *__restrict__ stats_out) {
+    render_body<true>(p, image, runs, shadow_runs, out, tile_counter, bounce_stack, stats_out);
 }
