@@ -20,14 +20,12 @@
 #include "rt_tables.h"
 
 extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__restrict__ image,
-                                            const RtRun *__restrict__ runs,
-                                            const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
+                                            const RtRun *__restrict__ runs, float *__restrict__ out,
                                             unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack);
 
 extern "C" __global__ void rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image,
-                                                  const RtRun *__restrict__ runs,
-                                                  const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
+                                                  const RtRun *__restrict__ runs, float *__restrict__ out,
                                                   unsigned int *__restrict__ tile_counter,
                                                   float4 *__restrict__ bounce_stack,
                                                   unsigned long long *__restrict__ stats_out);
@@ -67,10 +65,10 @@ struct rt_scene {
     float null_color[3] = {0.75f, 0.75f, 0.75f};
     /* packed tables (host copies) */
     std::vector<Quad> image;
-    std::vector<RtRun> runs, shadow_runs;
+    std::vector<RtRun> runs;
     RtParams base{};              /* table offsets filled at create */
     /* device copies */
-    void *d_image = nullptr, *d_runs = nullptr, *d_shadow_runs = nullptr;
+    void *d_image = nullptr, *d_runs = nullptr;
     /* scratch framebuffer for rt_render (host destination) */
     void *d_fb = nullptr;
     size_t d_fb_bytes = 0;
@@ -79,6 +77,7 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int tiles_per_grab_opt = 0;   /* 0 = auto */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
+    int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
     int n_clusters = 0;
@@ -148,6 +147,26 @@ void split_leaves(const rt_object_desc *objs, std::vector<int> ids, int leaf, st
     });
     split_leaves(objs, std::vector<int>(ids.begin(), ids.begin() + (long)mid), leaf, out);
     split_leaves(objs, std::vector<int>(ids.begin() + (long)mid, ids.end()), leaf, out);
+}
+
+/* axis of a +-unit axis vector (other components exactly +-0), or -1 */
+int unit_axis(const float v[3], float *sign) {
+    for (int k = 0; k < 3; ++k)
+        if (std::fabs(v[k]) == 1.0f && v[(k + 1) % 3] == 0.0f && v[(k + 2) % 3] == 0.0f) { *sign = v[k]; return k; }
+    return -1;
+}
+
+/* class of an axis-aligned finite plane (rt_tables.h), or -1 */
+int aa_class(const rt_object_desc &o, float *sn, float *sh, float *sv, int *a_axis, int *b_axis) {
+    if (o.kind != RT_KIND_FINITE_PLANE) return -1;
+    const int kn = unit_axis(o.normal, sn), kh = unit_axis(o.horizontal, sh), kv = unit_axis(o.vertical, sv);
+    if (kn < 0 || kh < 0 || kv < 0 || kn == kh || kn == kv || kh == kv) return -1;
+    const float vals[6] = {o.plane_origin[0], o.plane_origin[1], o.plane_origin[2], o.h_distance, o.v_distance,
+                           o.distance_to_origin};
+    for (float f : vals) if (!std::isfinite(f)) return -1;
+    if (o.h_distance < 0.0f || o.v_distance < 0.0f) return -1;
+    *a_axis = kh; *b_axis = kv;
+    return 2 * kn + (kh == (kn + 1) % 3 ? 0 : 1);
 }
 
 bool all_finite(const rt_object_desc &o) {
@@ -223,11 +242,18 @@ int pack_scene(rt_scene *s) {
     };
 
     s->runs.clear();
-    s->shadow_runs.clear();
     s->n_clusters = 0;
     /* Cluster/idx offsets are patched once the section bases are known. */
     struct Pending { size_t run_pos; bool shadow; int cluster_first, cidx_first; };
     std::vector<Pending> pending;
+    std::vector<int> aa_all;                         /* axis-aligned finite planes (Scene indices) */
+    std::vector<int> aa_rec_of((size_t)n, -1);       /* their AA test record (quad offset within aa_recs) */
+    std::vector<int> aa_cls_of((size_t)n, -1);
+    std::vector<char> clustered((size_t)n, 0);
+    std::vector<Quad> shadow_leaf_items, shadow_items;
+    std::vector<Quad> aa_recs;
+    struct PendingAA { size_t run_pos; bool shadow; int rec_first, cidx_first; };
+    std::vector<PendingAA> pending_aa;
 
     for (const Span &sp : spans) {
         const int first = sp.first, last = sp.first + sp.count;             /* [first, last) */
@@ -264,23 +290,44 @@ int pack_scene(rt_scene *s) {
                     const Leaf &L = leaves[(size_t)l];
                     const int member_off = (int)geom.size();
                     const int slot = (int)cidx.size() - cidx_first;
-                    for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); }
+                    for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); clustered[(size_t)i] = 1; }
                     clusters.push_back({{L.lo[0], L.lo[1], L.lo[2],
                                          bits_to_float((uint32_t)member_off | ((uint32_t)L.members.size() << 16))}});
                     clusters.push_back({{L.hi[0], L.hi[1], L.hi[2], bits_to_float((uint32_t)slot)}});
+                    if (in_shadow_all) {
+                        shadow_leaf_items.push_back({{L.lo[0], L.lo[1], L.lo[2],
+                            bits_to_float((uint32_t)RT_KIND_SPHERE_CLUSTERED | ((uint32_t)L.members.size() << 8) |
+                                          ((uint32_t)member_off << 16))}});
+                        shadow_leaf_items.push_back({{L.hi[0], L.hi[1], L.hi[2], 0.0f}});
+                    }
                 }
             }
             s->n_clusters += (int)leaves.size();
             pending.push_back(Pending{s->runs.size(), false, group_first, cidx_first});
             s->runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, n_groups, 0, 0});
-            if (in_shadow_all) {
-                pending.push_back(Pending{s->shadow_runs.size(), true, group_first, cidx_first});
-                s->shadow_runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, n_groups, 0, 0});
+        } else if (sp.kind == RT_KIND_FINITE_PLANE && s->aa_planes) {
+            /* axis-aligned members leave the in-order run for the class-sorted tables built below */
+            for (int i = first; i < last; ++i) emit_geometry(i);
+            int i = first;
+            while (i < last) {
+                float sn, sh, sv; int ka, kb;
+                const bool aa = aa_class(objs[i], &sn, &sh, &sv, &ka, &kb) >= 0;
+                int j = i;
+                while (j < last) {
+                    const bool aj = aa_class(objs[j], &sn, &sh, &sv, &ka, &kb) >= 0;
+                    if (aj != aa) break;
+                    ++j;
+                }
+                if (aa) {
+                    for (int k = i; k < j; ++k) aa_all.push_back(k);
+                } else {
+                    s->runs.push_back(RtRun{sp.kind, j - i, i, geom_off[(size_t)i]});
+                }
+                i = j;
             }
         } else {
             for (int i = first; i < last; ++i) emit_geometry(i);
             s->runs.push_back(RtRun{sp.kind, sp.count, first, geom_off[(size_t)first]});
-            if (!sp.light && s0 < s1) s->shadow_runs.push_back(RtRun{sp.kind, s1 - s0, s0, geom_off[(size_t)s0]});
         }
         if (geom.size() > RT_MAX_GEOM_QUADS) return fail(RT_ERR_CAPACITY, "geometry table too large");
     }
@@ -301,6 +348,30 @@ int pack_scene(rt_scene *s) {
         for (Pending &pd : pending) if (!pd.shadow) pd.run_pos = remap[pd.run_pos];
         s->runs.swap(merged);
     }
+    /* axis-aligned rectangles: one run per class, appended after every in-order run */
+    auto emit_aa = [&](const std::vector<int> &ids, bool shadow) {
+        for (int cls = 0; cls < 6; ++cls) {
+            const int rec_first = (int)(aa_recs.size() / RT_AA_QUADS), cidx_first = (int)cidx.size();
+            int count = 0;
+            for (int i : ids) {
+                float sn, sh, sv; int ka, kb;
+                if (aa_class(objs[i], &sn, &sh, &sv, &ka, &kb) != cls) continue;
+                const rt_object_desc &o = objs[i];
+                aa_rec_of[(size_t)i] = (int)aa_recs.size();
+                aa_cls_of[(size_t)i] = cls;
+                aa_recs.push_back({{o.distance_to_origin, sn, sh, sv}});
+                aa_recs.push_back({{o.plane_origin[ka], o.plane_origin[kb], o.h_distance, o.v_distance}});
+                cidx.push_back((uint32_t)i);
+                ++count;
+            }
+            if (!count) continue;
+            std::vector<RtRun> &list = s->runs;
+            (void)shadow;
+            pending_aa.push_back(PendingAA{list.size(), shadow, rec_first, cidx_first});
+            list.push_back(RtRun{RT_KIND_FINITE_AA + cls, count, 0, 0});
+        }
+    };
+    emit_aa(aa_all, false);
     for (int i = 0; i < n; ++i)
         objinfo[(size_t)i] = (uint32_t)geom_off[(size_t)i] | ((uint32_t)objs[i].kind << 16) |
                              ((uint32_t)mat_of[(size_t)i] << 20);
@@ -312,6 +383,87 @@ int pack_scene(rt_scene *s) {
     s->image.insert(s->image.end(), geom.begin(), geom.end());
     const int clusters_off = (int)s->image.size();
     s->image.insert(s->image.end(), clusters.begin(), clusters.end());
+    const int aa_off = (int)s->image.size();
+    s->image.insert(s->image.end(), aa_recs.begin(), aa_recs.end());
+    /* shadow items: every non-light object of the scan range in Scene order (clustered
+     * spheres are represented by their leaves, appended after) */
+    {
+        const float INF = INFINITY;
+        auto box_item = [&](const double lo[3], const double hi[3], uint32_t bits, uint32_t full_off, bool unbounded) {
+            double ext = 0.0, mag = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                ext = std::max(ext, hi[k] - lo[k]);
+                mag = std::max(mag, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+            }
+            const double pad = 1e-4 + 1e-4 * mag + 1e-2 * ext;
+            Quad q0, q1;
+            for (int k = 0; k < 3; ++k) {
+                const bool ok = !unbounded && std::isfinite(lo[k]) && std::isfinite(hi[k]) && std::isfinite(pad);
+                q0.v[k] = ok ? std::nextafter((float)(lo[k] - pad), -INF) : -INF;
+                q1.v[k] = ok ? std::nextafter((float)(hi[k] + pad), INF) : INF;
+            }
+            q0.v[3] = bits_to_float(bits);
+            q1.v[3] = bits_to_float(full_off);
+            shadow_items.push_back(q0);
+            shadow_items.push_back(q1);
+        };
+        for (int i = sb; i < se; ++i) {
+            const rt_object_desc &o = objs[i];
+            if (o.is_light || clustered[(size_t)i]) continue;
+            double lo[3], hi[3];
+            const uint32_t full = (uint32_t)geom_off[(size_t)i];
+            if (o.kind == RT_KIND_SPHERE) {
+                const double r = std::fabs((double)o.radius);
+                for (int k = 0; k < 3; ++k) { lo[k] = (double)o.origin[k] - r; hi[k] = (double)o.origin[k] + r; }
+                box_item(lo, hi, (uint32_t)RT_KIND_SPHERE | (full << 16), full, false);
+            } else if (o.kind == RT_KIND_INFINITE_PLANE) {
+                for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = 0.0; }
+                box_item(lo, hi, (uint32_t)RT_KIND_INFINITE_PLANE | (full << 16), full, true);
+            } else {
+                /* The hit region is {p on the plane : 0 <= (p-po).h <= h_dist, 0 <= (p-po).v <= v_dist}
+                 * (src/SceneFinitePlane.cpp:117-124).  h and v need be neither orthogonal to each
+                 * other nor to the normal (axis constructor with arbitrary vectors), so the
+                 * corners come from solving  u.n = 0, u.h = x, u.v = y  for u = p - po. */
+                bool unbounded = false;
+                for (int k = 0; k < 3; ++k) { lo[k] = 1e300; hi[k] = -1e300; }
+                {
+                    const double n[3] = {o.normal[0], o.normal[1], o.normal[2]};
+                    const double h[3] = {o.horizontal[0], o.horizontal[1], o.horizontal[2]};
+                    const double v[3] = {o.vertical[0], o.vertical[1], o.vertical[2]};
+                    auto cross3 = [](const double a[3], const double c[3], double r[3]) {
+                        r[0] = a[1] * c[2] - a[2] * c[1]; r[1] = a[2] * c[0] - a[0] * c[2]; r[2] = a[0] * c[1] - a[1] * c[0];
+                    };
+                    double hv[3], vn[3], nh[3];
+                    cross3(h, v, hv); cross3(v, n, vn); cross3(n, h, nh);
+                    const double det = n[0] * hv[0] + n[1] * hv[1] + n[2] * hv[2];
+                    if (!(std::fabs(det) > 1e-6) || !std::isfinite(det)) {
+                        unbounded = true;
+                    } else {
+                        for (int a = 0; a < 2; ++a)
+                            for (int c = 0; c < 2; ++c) {
+                                const double x = a * (double)o.h_distance, y = c * (double)o.v_distance;
+                                for (int k = 0; k < 3; ++k) {          /* u = (x (v x n) + y (n x h)) / det */
+                                    const double u = (x * vn[k] + y * nh[k]) / det;
+                                    const double pk = (double)o.plane_origin[k] + u;
+                                    lo[k] = std::min(lo[k], pk);
+                                    hi[k] = std::max(hi[k], pk);
+                                }
+                            }
+                    }
+                }
+                if (unbounded) { for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = 0.0; } }
+                if (aa_rec_of[(size_t)i] >= 0)
+                    box_item(lo, hi, (uint32_t)(RT_KIND_FINITE_AA + aa_cls_of[(size_t)i]) |
+                                         ((uint32_t)(aa_off + aa_rec_of[(size_t)i]) << 16), full, unbounded);
+                else
+                    box_item(lo, hi, (uint32_t)RT_KIND_FINITE_PLANE | (full << 16), full, unbounded);
+            }
+        }
+        shadow_items.insert(shadow_items.end(), shadow_leaf_items.begin(), shadow_leaf_items.end());
+    }
+    b.shadow_items_off = (int)s->image.size();
+    b.n_shadow_items = (int)(shadow_items.size() / 2);
+    s->image.insert(s->image.end(), shadow_items.begin(), shadow_items.end());
     const int groups_off = (int)s->image.size();
     for (size_t k = 0; k < groups.size(); k += RT_CLUSTER_QUADS) {      /* leaf index -> absolute quad offset */
         uint32_t leaf_index;
@@ -332,14 +484,19 @@ int pack_scene(rt_scene *s) {
     s->image.resize(s->image.size() + (cidx.size() + 3) / 4, Quad{{0, 0, 0, 0}});
     if (!cidx.empty()) std::memcpy(s->image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
     for (const Pending &pd : pending) {
-        RtRun &run = pd.shadow ? s->shadow_runs[pd.run_pos] : s->runs[pd.run_pos];
+        RtRun &run = s->runs[pd.run_pos];
         run.geom_off = groups_off + pd.cluster_first * RT_CLUSTER_QUADS;
         run.first = cidx_off * 4 + pd.cidx_first;          /* u32 index of the run's member-index table */
+    }
+    for (const PendingAA &pa : pending_aa) {
+        RtRun &run = s->runs[pa.run_pos];
+        run.geom_off = aa_off + pa.rec_first * RT_AA_QUADS;
+        run.first = cidx_off * 4 + pa.cidx_first;
     }
     if (s->image.empty()) s->image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
     b.image_quads = (int)s->image.size();
     b.n_runs = (int)s->runs.size();
-    b.n_shadow_runs = (int)s->shadow_runs.size();
+    b.n_clusters = s->n_clusters;
     b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
     for (int c = 0; c < 3; ++c) b.null_color[c] = s->null_color[c];
     if ((size_t)b.image_quads * 16 > RT_MAX_LDS_BYTES)
@@ -376,7 +533,6 @@ int upload_scene(rt_scene *s) {
     HIP_TRY(hipSetDevice(s->device));
     if (s->d_image) { HIP_TRY(hipFree(s->d_image)); s->d_image = nullptr; }
     if (s->d_runs) { HIP_TRY(hipFree(s->d_runs)); s->d_runs = nullptr; }
-    if (s->d_shadow_runs) { HIP_TRY(hipFree(s->d_shadow_runs)); s->d_shadow_runs = nullptr; }
     hipEvent_t t0, t1;
     HIP_TRY(hipEventCreate(&t0));
     HIP_TRY(hipEventCreate(&t1));
@@ -384,13 +540,9 @@ int upload_scene(rt_scene *s) {
     const size_t image_bytes = s->image.size() * sizeof(Quad);
     HIP_TRY(hipMalloc(&s->d_image, image_bytes));
     HIP_TRY(hipMalloc(&s->d_runs, (s->runs.size() + 1) * sizeof(RtRun)));
-    HIP_TRY(hipMalloc(&s->d_shadow_runs, (s->shadow_runs.size() + 1) * sizeof(RtRun)));
     HIP_TRY(hipMemcpy(s->d_image, s->image.data(), image_bytes, hipMemcpyHostToDevice));
     if (!s->runs.empty())
         HIP_TRY(hipMemcpy(s->d_runs, s->runs.data(), s->runs.size() * sizeof(RtRun), hipMemcpyHostToDevice));
-    if (!s->shadow_runs.empty())
-        HIP_TRY(hipMemcpy(s->d_shadow_runs, s->shadow_runs.data(), s->shadow_runs.size() * sizeof(RtRun),
-                          hipMemcpyHostToDevice));
     HIP_TRY(hipEventRecord(t1, nullptr));
     HIP_TRY(hipEventSynchronize(t1));
     float ms = 0.f;
@@ -547,14 +699,12 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if (d_stats)
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
                            stream, p, reinterpret_cast<const float4 *>(s->d_image),
-                           reinterpret_cast<const RtRun *>(s->d_runs),
-                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter,
+                           reinterpret_cast<const RtRun *>(s->d_runs), d_out, counter,
                            reinterpret_cast<float4 *>(s->d_stack), d_stats);
     else
         hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
-                           reinterpret_cast<const RtRun *>(s->d_runs),
-                           reinterpret_cast<const RtRun *>(s->d_shadow_runs), d_out, counter,
+                           reinterpret_cast<const RtRun *>(s->d_runs), d_out, counter,
                            reinterpret_cast<float4 *>(s->d_stack));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
@@ -610,7 +760,6 @@ int rt_scene_destroy(rt_scene *s) {
         for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].stop); }
     if (s->d_image) (void)hipFree(s->d_image);
     if (s->d_runs) (void)hipFree(s->d_runs);
-    if (s->d_shadow_runs) (void)hipFree(s->d_shadow_runs);
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_stack) (void)hipFree(s->d_stack);
@@ -755,6 +904,14 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "grid_mult")) {
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "grid_mult must be in [0, 64]");
         s->grid_mult = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "aa_planes")) {
+        const int old = s->aa_planes;
+        s->aa_planes = value != 0;
+        int rc = pack_scene(s);
+        if (rc == RT_OK) rc = upload_scene(s);
+        if (rc) { s->aa_planes = old; return rc; }
         return RT_OK;
     }
     if (!std::strcmp(key, "cluster_leaf") || !std::strcmp(key, "cluster_group")) {

@@ -163,6 +163,57 @@ __device__ __forceinline__ void finite_plane_distance(const float4 *g, const V3 
     }
 }
 
+/* Axis-aligned rectangles (everything Scene::makeSceneBox builds,
+ * src/Scene.cpp:392-416: normal, horizontal and vertical are +-unit axes).
+ * With n = sn*e_n, h = sh*e_a, v = sv*e_b the reference's dot products reduce to
+ * one multiplication by +-1 plus additions of +-0:
+ *     o.n = (o_n*sn + (+-0)) + (+-0),   x = PO.h = ((+-0) + PO_a*sh) + (+-0), ...
+ * For a ray whose origin and direction are all FINITE those zeros can only
+ * change the sign of a zero result, and a zero numerator, denominator, x or y
+ * takes the same branch whatever its sign (t = +-0 is rejected by `t < 1E-5`,
+ * `denom == 0` and `x < 0` do not see the sign).  So, in coordinates permuted
+ * to (n, a, b), SceneFinitePlane::collision (src/SceneFinitePlane.cpp:86-124)
+ * is evaluated with a third of the arithmetic and an identical outcome.  Rays
+ * with a non-finite component take the general routine instead (inf*0 = NaN
+ * would differ).  Record: r0 = {dto, sn, sh, sv}, r1 = {po_a, po_b, h_dist, v_dist}
+ * (h_dist, v_dist >= 0). */
+__device__ __forceinline__ void aa_rectangle_distance(const float4 r0, const float4 r1, const V3 op, const V3 dp,
+                                                      const float bound, bool *hit, float *dist) {
+    const float numerator = -r0.x - op.x * r0.y;
+    const float denom = dp.x * r0.y;
+    const bool candidate = plane_candidate(numerator, denom, bound);
+    *hit = false;
+    *dist = 0.0f;
+    if (wave_any(candidate)) {
+        const float t = numerator / denom;
+        const float pa = dp.y * t + op.y;
+        const float pb = dp.z * t + op.z;
+        const float x = (pa - r1.x) * r0.z;
+        const float y = (pb - r1.y) * r0.w;
+        const bool miss = (t <= 9.99999974737875e-06f) || (x < 0) || (x > r1.z) || (y < 0) || (y > r1.w);
+        *hit = candidate && !miss;
+        *dist = t;
+    }
+}
+
+/* components of v in the order (normal axis, horizontal axis, vertical axis) of an AA class:
+ * class = 2*n_axis + (h_axis == (n_axis+1)%3 ? 0 : 1) */
+__device__ __forceinline__ V3 aa_permute(const V3 v, const int cls) {
+    switch (cls) {
+    case 0: return mk(v.x, v.y, v.z);
+    case 1: return mk(v.x, v.z, v.y);
+    case 2: return mk(v.y, v.z, v.x);
+    case 3: return mk(v.y, v.x, v.z);
+    case 4: return mk(v.z, v.x, v.y);
+    default: return mk(v.z, v.y, v.x);
+    }
+}
+
+__device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
+    /* a NaN or infinity in any component makes the sum non-finite */
+    return isfinite((fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)));
+}
+
 /* Conservative box test for clustered sphere runs (rt_tables.h).  The box
  * [lo, hi] (already inflated on the host by 1 % of its largest extent + 1e-4)
  * contains every member sphere.  A member can only be a CANDIDATE of
@@ -263,6 +314,29 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
                 st_wave(st, ST_WAVE_PLANE_TESTS); infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, best, &hit, &t);
                 if (hit && t < best) { best = t; best_idx = run.first + i; }
             }
+        } else if (run.kind >= RT_KIND_FINITE_AA) {
+            /* class-sorted, hence out of Scene order: ties go to the lower Scene index */
+            const uint32_t *ids = reinterpret_cast<const uint32_t *>(lds) + run.first;
+            if (wave_any(!ray_is_finite(o, d))) {
+                for (int i = 0; i < run.count; ++i) {                       /* general routine on the full record */
+                    const int idx = (int)ids[i];
+                    const float4 *full = lds + (reinterpret_cast<const uint32_t *>(lds)[p.objinfo_off * 4 + idx] & 0xFFFFu);
+                    bool hit; float t;
+                    st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(full, o, d, best, &hit, &t);
+                    if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
+                }
+            } else {
+                const V3 op = aa_permute(o, run.kind - RT_KIND_FINITE_AA), dp = aa_permute(d, run.kind - RT_KIND_FINITE_AA);
+#pragma unroll 2
+                for (int i = 0; i < run.count; ++i) {
+                    bool hit; float t;
+                    st_wave(st, ST_WAVE_PLANE_TESTS); aa_rectangle_distance(g[2 * i], g[2 * i + 1], op, dp, best, &hit, &t);
+                    if (wave_any(hit)) {
+                        const int idx = (int)ids[i];
+                        if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
+                    }
+                }
+            }
         } else {
 #pragma unroll 2
             for (int i = 0; i < run.count; ++i) {
@@ -276,71 +350,98 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
     *best_idx_out = best_idx;
 }
 
-/* inShadeCollisionDetection, src/RayTracer.cpp:709-739: any non-light object
- * of the scan range with distance < dist_to_light blocks.  A boolean OR, so
- * the scan order is free; the wave stops when every lane is blocked. */
+/* wavefront-wide min / max of a per-lane value; call only where all 64 lanes are active */
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+/* inShade + inShadeCollisionDetection, src/RayTracer.cpp:709-771: any non-light
+ * object of the scan range with distance < dist_to_light blocks the light.
+ *
+ * Must be called by the whole (converged) wavefront; `active` says whether
+ * this lane has a shadow ray at all.  The wavefront first culls the shadow
+ * ITEMS (rt_tables.h: one per object, or per leaf of a clustered sphere run)
+ * cooperatively: the 64 shadow segments all end at the same light, so they lie
+ * inside the bounding box B of {their origins} + {light}; LANE i tests ITEM
+ * base+i's box against B and one ballot yields the candidate mask.  Only
+ * candidates get the exact per-lane tests.  An object can only block if the
+ * reference finds a hit with 0 < distance < dist_to_light; that hit point is
+ * within rounding of the segment and of the object, so both boxes contain it
+ * once grown by `fuzz` (the item boxes are inflated on the host, B here: 4e-3 of
+ * its size covers the sphere routine's distance-dependent slack, see
+ * box_needed()).  A NaN bound compares "overlapping".  Blocking is a boolean OR,
+ * so order does not matter. */
 template <bool kStats>
-__device__ __forceinline__ bool in_shade(const RtParams &p, const RtRun *__restrict__ shadow_runs,
-                                         const float4 *lds, const V3 o, const V3 d, const float dist_to_light,
+__device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, const bool active,
+                                         const V3 o, const V3 d, const float dist_to_light, const V3 light,
                                          Stats<kStats> &st) {
-    bool blocked = false;
-    st_lane(st, ST_SHADOW_RAYS, true);
+    bool blocked = !active;
+    if (p.n_shadow_items == 0) return false;
+    st_lane(st, ST_SHADOW_RAYS, active);
     st_wave(st, ST_WAVE_SHADOW);
-    for (int r = 0; r < p.n_shadow_runs; ++r) {
-        if (!wave_any(!blocked)) break;
-        const RtRun run = shadow_runs[r];
-        const float4 *g = lds + run.geom_off;
-        if (run.kind == RT_KIND_SPHERE) {
-            for (int i = 0; i < run.count; i += 2) {
-                if (!wave_any(!blocked)) break;
-                bool hit; float t;
-                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, true); sphere_distance(g[i], o, d, &hit, &t);
+
+    const float inf = __builtin_huge_valf();
+    float lox = fminf(wave_min(active ? o.x : inf), light.x), hix = fmaxf(wave_max(active ? o.x : -inf), light.x);
+    float loy = fminf(wave_min(active ? o.y : inf), light.y), hiy = fmaxf(wave_max(active ? o.y : -inf), light.y);
+    float loz = fminf(wave_min(active ? o.z : inf), light.z), hiz = fmaxf(wave_max(active ? o.z : -inf), light.z);
+    const float fuzz = 4.0e-3f * ((hix - lox) + (hiy - loy) + (hiz - loz)) + 1.0e-4f;
+    lox -= fuzz; loy -= fuzz; loz -= fuzz; hix += fuzz; hiy += fuzz; hiz += fuzz;
+
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
+    V3 inv = mk(0.0f, 0.0f, 0.0f);
+    if (p.n_clusters) inv = approx_inverse(d);
+    const float4 *items = lds + p.shadow_items_off;
+    for (int base = 0; base < p.n_shadow_items; base += 64) {
+        const int mine = min(base + lane, p.n_shadow_items - 1);
+        const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
+        const bool apart = (b0.x > hix) || (b1.x < lox) || (b0.y > hiy) || (b1.y < loy) || (b0.z > hiz) || (b1.z < loz);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(base + lane < p.n_shadow_items && !apart);
+        while (mask != 0ull) {
+            const int item = base + (__ffsll((long long)mask) - 1);
+            mask &= mask - 1ull;
+            if (!wave_any(!blocked)) return true;
+            const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
+            const uint32_t bits = __float_as_uint(i0.w);
+            const int kind = (int)(bits & 15u);
+            const float4 *g = lds + (bits >> 16);
+            bool hit; float t;
+            if (kind == RT_KIND_SPHERE) {
+                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, !blocked);
+                sphere_distance(g[0], o, d, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
-                if (i + 1 < run.count) {
-                    st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, true); sphere_distance(g[i + 1], o, d, &hit, &t);
-                    blocked = blocked || (hit && t < dist_to_light);
-                }
-            }
-        } else if (run.kind == RT_KIND_SPHERE_CLUSTERED) {
-            const V3 inv = approx_inverse(d);
-            for (int gi = 0; gi < run.count; ++gi) {
-                if (!wave_any(!blocked)) break;
-                const float4 g0 = g[gi * RT_CLUSTER_QUADS], g1 = g[gi * RT_CLUSTER_QUADS + 1];
+            } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a leaf of a clustered run */
                 st_wave(st, ST_WAVE_BOX_TESTS);
-                if (!wave_any(!blocked && box_needed(g0, g1, o, inv, dist_to_light))) continue;
-                const float4 *leaves = lds + __float_as_uint(g0.w);
-                const int n_leaves = (int)__float_as_uint(g1.w);
-                for (int c = 0; c < n_leaves; ++c) {
-                    const float4 c0 = leaves[c * RT_CLUSTER_QUADS], c1 = leaves[c * RT_CLUSTER_QUADS + 1];
-                    st_wave(st, ST_WAVE_BOX_TESTS);
-                    const bool lane_needs = !blocked && box_needed(c0, c1, o, inv, dist_to_light);
-                    if (!wave_any(lane_needs)) continue;
-                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
-                    const int n = (int)(__float_as_uint(c0.w) >> 16);
+                const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
+                if (wave_any(lane_needs)) {
+                    const int n = (int)((bits >> 8) & 255u);
 #pragma unroll 2
                     for (int i = 0; i < n; ++i) {
-                        bool hit; float t;
-                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs); sphere_distance(m[i], o, d, &hit, &t);
+                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+                        sphere_distance(g[i], o, d, &hit, &t);
                         blocked = blocked || (hit && t < dist_to_light);
                     }
                 }
-            }
-        } else if (run.kind == RT_KIND_INFINITE_PLANE) {
-            for (int i = 0; i < run.count; ++i) {
-                bool hit; float t;
-                st_wave(st, ST_WAVE_PLANE_TESTS); infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, dist_to_light, &hit, &t);
+            } else if (kind == RT_KIND_INFINITE_PLANE) {
+                st_wave(st, ST_WAVE_PLANE_TESTS);
+                infinite_plane_distance(g[0], o, d, dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
-            }
-        } else {
-            for (int i = 0; i < run.count; i += 2) {
-                if (!wave_any(!blocked)) break;
-                bool hit; float t;
-                st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
+            } else if (kind >= RT_KIND_FINITE_AA && finite_rays) {
+                st_wave(st, ST_WAVE_PLANE_TESTS);
+                const int cls = kind - RT_KIND_FINITE_AA;
+                aa_rectangle_distance(g[0], g[1], aa_permute(o, cls), aa_permute(d, cls), dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
-                if (i + 1 < run.count) {
-                    st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(g + (i + 1) * RT_PLANE_QUADS, o, d, dist_to_light, &hit, &t);
-                    blocked = blocked || (hit && t < dist_to_light);
-                }
+            } else {                                             /* finite plane, general routine on the full record */
+                st_wave(st, ST_WAVE_PLANE_TESTS);
+                finite_plane_distance(lds + __float_as_uint(i1.w), o, d, dist_to_light, &hit, &t);
+                blocked = blocked || (hit && t < dist_to_light);
             }
         }
     }
@@ -370,7 +471,7 @@ __device__ __forceinline__ V3 entry_colour(const RtParams &p, const float4 *lds,
 
 template <bool kStats>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
-                                            const RtRun *__restrict__ runs, const RtRun *__restrict__ shadow_runs,
+                                            const RtRun *__restrict__ runs,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack,
                                             unsigned long long *__restrict__ stats_out) {
@@ -451,15 +552,18 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     for (int level = 0; level <= p.max_depth; ++level) {
         if (__ballot(alive) == 0ull) break;
         levels = level + 1;
+        /* ---- phase 1 (per lane): nearest hit and the winner's CollisionObject ---- */
+        bool shade = false;          /* this lane hit a non-light object and shades it */
+        V3 P = o, N = d, object_color = null_color;
+        float diffuse_factor = 0.0f, specular_factor = 0.0f, reflective_factor = 0.0f;
+        int idx = -1, texsel = 0;
         if (alive) {
             float t;
-            int idx;
             nearest_hit<kStats>(p, runs, lds, o, d, &t, &idx, st);
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
                 alive = false;
             } else {
-                /* ---- build the winner's CollisionObject ---- */
                 const uint32_t info = lds_u32[p.objinfo_off * 4 + idx];
                 const float4 *g = lds + (info & 0xFFFFu);
                 const int kind = (int)((info >> 16) & 3u);
@@ -467,9 +571,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 const float4 m0 = lds[p.mat_off + mat * RT_MAT_QUADS];
                 const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
                 const uint32_t mbits = __float_as_uint(m1.w);
-                const float diffuse_factor = m0.w, specular_factor = m1.x, reflective_factor = m1.y;
-                V3 P, N;
-                int texsel = 0;
+                diffuse_factor = m0.w; specular_factor = m1.x; reflective_factor = m1.y;
                 if (kind == RT_KIND_SPHERE) {                /* src/SceneSphere.cpp:118-149 */
                     const float4 s = g[0];
                     P = add3(scale3(d, t), o);
@@ -489,72 +591,81 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                     N = (dot3(xyz(q0), d) < 0) ? xyz(q0) : xyz(q4);
                     P = add3(ip, scale3(N, (float)1E-3));
                 }
-                const V3 object_color = entry_colour(p, lds, m0, mbits, texsel);
-
+                object_color = entry_colour(p, lds, m0, mbits, texsel);
                 if (mbits & 1u) {                            /* hit a light: :520-527 */
                     C = scale3(object_color, m1.z);
                     alive = false;
                 } else {
-                    /* CollisionObject ctor, src/SceneObject.h:62-92 */
-                    const V3 normal_dir = normalize3(N);           /* Ray(point, normal) re-normalises */
-                    const float n_dot_incoming = dot3(N, d);
-                    V3 final_color = mk(0.0f, 0.0f, 0.0f);
+                    shade = true;
+                }
+            }
+        }
 
-                    /* lights in Scene index order, :540-591 */
-                    for (int l = 0; l < p.n_lights; ++l) {
-                        const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
-                        const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
-                        /* inShade, :743-771 */
-                        const V3 dir = sub3(xyz(l0), P);
-                        const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
-                        const V3 light_ray = normalize3(dir);      /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
-                        if (!in_shade<kStats>(p, shadow_runs, lds, P, light_ray, dist_to_light, st)) {
-                            const V3 light_color = xyz(l1);
-                            /* cosineShade, :654-701 */
-                            if (diffuse_factor > (float)0) {
-                                float cosine_dot_factor = dot3(normal_dir, light_ray);
-                                if (cosine_dot_factor > (float)0) {
-                                    const float factor = cosine_dot_factor * diffuse_factor * l0.w;
-                                    final_color.x += factor * object_color.x * light_color.x;
-                                    final_color.y += factor * object_color.y * light_color.y;
-                                    final_color.z += factor * object_color.z * light_color.z;
-                                }
-                                final_color.x = (final_color.x > 1.0f) ? 1.0f : final_color.x;
-                                final_color.y = (final_color.y > 1.0f) ? 1.0f : final_color.y;
-                                final_color.z = (final_color.z > 1.0f) ? 1.0f : final_color.z;
-                            }
-                            /* specular, :561-588 */
-                            const V3 Nn = normalize3(normal_dir);  /* third normalisation, :566-567 */
-                            const V3 R = sub3(light_ray, scale3(Nn, 2.0f * dot3(light_ray, Nn)));
-                            const float dot = dot3(d, R);
-                            if (dot > (float)0) {
-                                float pow_factor = dot;
-#pragma unroll
-                                for (int j = 0; j < 19; ++j) pow_factor *= dot;
-                                const float spec_factor = pow_factor * specular_factor;
-                                final_color = add3(final_color, scale3(light_color, spec_factor));
-                            }
+        /* ---- phase 2 (whole wavefront, converged): lights in Scene index order, :540-591.
+         * Every lane walks the light loop so that the shadow scan can cull scene
+         * items for the wavefront as a whole; lanes with nothing to shade carry
+         * shade == false through it. ---- */
+        V3 final_color = mk(0.0f, 0.0f, 0.0f);
+        /* CollisionObject ctor, src/SceneObject.h:62-92 */
+        const V3 normal_dir = normalize3(N);                 /* Ray(point, normal) re-normalises */
+        const float n_dot_incoming = dot3(N, d);
+        if (wave_any(shade)) {
+            for (int l = 0; l < p.n_lights; ++l) {
+                const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
+                const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
+                /* inShade, :743-771 */
+                const V3 dir = sub3(xyz(l0), P);
+                const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+                const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
+                const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), st);
+                if (shade && !blocked) {
+                    const V3 light_color = xyz(l1);
+                    /* cosineShade, :654-701 */
+                    if (diffuse_factor > (float)0) {
+                        float cosine_dot_factor = dot3(normal_dir, light_ray);
+                        if (cosine_dot_factor > (float)0) {
+                            const float factor = cosine_dot_factor * diffuse_factor * l0.w;
+                            final_color.x += factor * object_color.x * light_color.x;
+                            final_color.y += factor * object_color.y * light_color.y;
+                            final_color.z += factor * object_color.z * light_color.z;
                         }
+                        final_color.x = (final_color.x > 1.0f) ? 1.0f : final_color.x;
+                        final_color.y = (final_color.y > 1.0f) ? 1.0f : final_color.y;
+                        final_color.z = (final_color.z > 1.0f) ? 1.0f : final_color.z;
                     }
-
-                    if (reflective_factor > (float)0) {      /* :595-604 */
-                        const V3 reflected = mk(-2 * N.x * n_dot_incoming + d.x,
-                                                -2 * N.y * n_dot_incoming + d.y,
-                                                -2 * N.z * n_dot_incoming + d.z);
-                        float4 e;
-                        e.x = final_color.x; e.y = final_color.y; e.z = final_color.z;
-                        e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
-                        stack[level * blockDim.x + threadIdx.x] = e;
-                        top = level + 1;
-                        o = P;
-                        d = normalize3(reflected);           /* Ray(point, reflected) */
-                        /* if the loop ends now the call at max_depth+1 returns NULL_COLOR, :454-455 */
-                        C = null_color;
-                    } else {
-                        C = final_color;
-                        alive = false;
+                    /* specular, :561-588 */
+                    const V3 Nn = normalize3(normal_dir);    /* third normalisation, :566-567 */
+                    const V3 R = sub3(light_ray, scale3(Nn, 2.0f * dot3(light_ray, Nn)));
+                    const float dot = dot3(d, R);
+                    if (dot > (float)0) {
+                        float pow_factor = dot;
+#pragma unroll
+                        for (int j = 0; j < 19; ++j) pow_factor *= dot;
+                        const float spec_factor = pow_factor * specular_factor;
+                        final_color = add3(final_color, scale3(light_color, spec_factor));
                     }
                 }
+            }
+        }
+
+        /* ---- phase 3 (per lane): reflect or finish, :595-604 ---- */
+        if (shade) {
+            if (reflective_factor > (float)0) {
+                const V3 reflected = mk(-2 * N.x * n_dot_incoming + d.x,
+                                        -2 * N.y * n_dot_incoming + d.y,
+                                        -2 * N.z * n_dot_incoming + d.z);
+                float4 e;
+                e.x = final_color.x; e.y = final_color.y; e.z = final_color.z;
+                e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
+                stack[level * blockDim.x + threadIdx.x] = e;
+                top = level + 1;
+                o = P;
+                d = normalize3(reflected);                   /* Ray(point, reflected) */
+                /* if the loop ends now the call at max_depth+1 returns NULL_COLOR, :454-455 */
+                C = null_color;
+            } else {
+                C = final_color;
+                alive = false;
             }
         }
     }
@@ -601,16 +712,15 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 
 extern "C" __global__ void __launch_bounds__(512)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
-                 const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
-                 unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack) {
-    render_body<false>(p, image, runs, shadow_runs, out, tile_counter, bounce_stack, nullptr);
+                 float *__restrict__ out, unsigned int *__restrict__ tile_counter,
+                 float4 *__restrict__ bounce_stack) {
+    render_body<false>(p, image, runs, out, tile_counter, bounce_stack, nullptr);
 }
 
 /* the counting build: same arithmetic and control flow plus work counters */
 extern "C" __global__ void __launch_bounds__(512)
 rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
-                       const RtRun *__restrict__ shadow_runs, float *__restrict__ out,
-                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                       unsigned long long *__restrict__ stats_out) {
-    render_body<true>(p, image, runs, shadow_runs, out, tile_counter, bounce_stack, stats_out);
+                       float *__restrict__ out, unsigned int *__restrict__ tile_counter,
+                       float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out) {
+    render_body<true>(p, image, runs, out, tile_counter, bounce_stack, stats_out);
 }

@@ -38,13 +38,23 @@
  * because ties are broken on the Scene index (lexicographic min of (distance,
  * index) is what an in-order scan with a strict `<` computes).
  *
+ * Shadow items.  The shadow scan (src/RayTracer.cpp:709-739) walks a table of
+ * ITEMS: one per non-light object of the scan range, except that a clustered
+ * sphere run contributes one item per leaf.  2 quads per item:
+ *   {box lo.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
+ *   {box hi.xyz, bits(quad offset of the plane's full 5-quad record)}
+ * kind = RT_KIND_SPHERE / _INFINITE_PLANE / _FINITE_PLANE, RT_KIND_SPHERE_CLUSTERED
+ * for a leaf (count = members), RT_KIND_FINITE_AA + class for an axis-aligned
+ * rectangle (geometry offset = its AA test record).  The box (inflated on the
+ * host) contains the object; an infinite plane's box is all of space.  The
+ * wavefront tests 64 item boxes at once, one per lane (rt_kernel.hip, in_shade).
+ *
  * The object list is additionally described as RUNS of consecutive objects of
  * one kind and one light flag (an int4 each, kept in global memory and read
- * with scalar loads because the run index is wave-uniform).  Runs preserve
- * Scene index order, so "first strictly-smaller distance wins"
- * (src/RayTracer.cpp:75-78) needs no tie-break logic.  A second run list holds
- * the non-light objects inside the shadow scan range
- * (src/RayTracer.cpp:716-729).
+ * with scalar loads because the run index is wave-uniform), used by the
+ * nearest-hit scan.  In-order runs preserve Scene index order, so "first
+ * strictly-smaller distance wins" (src/RayTracer.cpp:75-78) needs no tie-break
+ * there; class-sorted and clustered runs break ties on the Scene index.
  */
 #ifndef RT_TABLES_H_
 #define RT_TABLES_H_
@@ -61,6 +71,14 @@
 /* run kinds: RT_KIND_* of rt_capi.h (0 sphere, 1 infinite plane, 2 finite
  * plane) plus a long sphere run regrouped into spatial clusters */
 #define RT_KIND_SPHERE_CLUSTERED 3
+/* axis-aligned finite planes, six classes by axis permutation: kind = 4 + class,
+ * class = 2*normal_axis + (horizontal_axis == (normal_axis+1)%3 ? 0 : 1).
+ * Test records (2 quads): {dto, sn, sh, sv}, {po_a, po_b, h_dist, v_dist} in
+ * the permuted coordinates (n, a, b); `first` = u32 index of the run's Scene
+ * index table.  The full 5-quad record of each plane is kept too (winner
+ * record, non-finite rays). */
+#define RT_KIND_FINITE_AA 4
+#define RT_AA_QUADS 2
 
 #define RT_MAX_GEOM_QUADS 65535   /* 16-bit geometry offset in objinfo */
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
@@ -84,7 +102,9 @@ typedef struct RtParams {
     float null_color[3];
     int32_t W, H, x0, x1, max_depth;
     /* tables */
-    int32_t n_runs, n_shadow_runs, n_lights;
+    int32_t n_runs, n_lights;
+    int32_t n_shadow_items, shadow_items_off;            /* shadow item table (quads), see below */
+    int32_t n_clusters;                                  /* leaves of clustered sphere runs       */
     int32_t image_quads;                 /* quads staged into LDS */
     int32_t lights_off, mat_off, tex_off, objinfo_off;   /* quad offsets */
     /* tiling: a wavefront renders tile_x x tile_z pixels, tile_x * tile_z == 64 */
