@@ -250,7 +250,7 @@ int pack_scene(rt_scene *s) {
     std::vector<int> aa_rec_of((size_t)n, -1);       /* their AA test record (quad offset within aa_recs) */
     std::vector<int> aa_cls_of((size_t)n, -1);
     std::vector<char> clustered((size_t)n, 0);
-    std::vector<Quad> shadow_leaf_items, shadow_items;
+    std::vector<Quad> shadow_group_items, shadow_items;
     std::vector<Quad> aa_recs;
     struct PendingAA { size_t run_pos; bool shadow; int rec_first, cidx_first; };
     std::vector<PendingAA> pending_aa;
@@ -286,6 +286,14 @@ int pack_scene(rt_scene *s) {
                 groups.push_back({{ball[0].lo[0], ball[0].lo[1], ball[0].lo[2],
                                    bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS))}});
                 groups.push_back({{ball[0].hi[0], ball[0].hi[1], ball[0].hi[2], bits_to_float((uint32_t)(l1 - l0))}});
+                if (in_shadow_all) {
+                    /* shadow item for the group: geometry offset = its first leaf record (index into
+                     * the leaf section, made absolute below), count = its leaves */
+                    shadow_group_items.push_back({{ball[0].lo[0], ball[0].lo[1], ball[0].lo[2],
+                                                   bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS))}});
+                    shadow_group_items.push_back({{ball[0].hi[0], ball[0].hi[1], ball[0].hi[2],
+                                                   bits_to_float((uint32_t)(l1 - l0))}});
+                }
                 for (int l = l0; l < l1; ++l) {
                     const Leaf &L = leaves[(size_t)l];
                     const int member_off = (int)geom.size();
@@ -294,12 +302,6 @@ int pack_scene(rt_scene *s) {
                     clusters.push_back({{L.lo[0], L.lo[1], L.lo[2],
                                          bits_to_float((uint32_t)member_off | ((uint32_t)L.members.size() << 16))}});
                     clusters.push_back({{L.hi[0], L.hi[1], L.hi[2], bits_to_float((uint32_t)slot)}});
-                    if (in_shadow_all) {
-                        shadow_leaf_items.push_back({{L.lo[0], L.lo[1], L.lo[2],
-                            bits_to_float((uint32_t)RT_KIND_SPHERE_CLUSTERED | ((uint32_t)L.members.size() << 8) |
-                                          ((uint32_t)member_off << 16))}});
-                        shadow_leaf_items.push_back({{L.hi[0], L.hi[1], L.hi[2], 0.0f}});
-                    }
                 }
             }
             s->n_clusters += (int)leaves.size();
@@ -459,7 +461,17 @@ int pack_scene(rt_scene *s) {
                     box_item(lo, hi, (uint32_t)RT_KIND_FINITE_PLANE | (full << 16), full, unbounded);
             }
         }
-        shadow_items.insert(shadow_items.end(), shadow_leaf_items.begin(), shadow_leaf_items.end());
+        for (size_t k = 0; k + 1 < shadow_group_items.size(); k += 2) {
+            uint32_t leaf_index, n_leaves;
+            std::memcpy(&leaf_index, &shadow_group_items[k].v[3], 4);
+            std::memcpy(&n_leaves, &shadow_group_items[k + 1].v[3], 4);
+            Quad q0 = shadow_group_items[k], q1 = shadow_group_items[k + 1];
+            q0.v[3] = bits_to_float((uint32_t)RT_KIND_SPHERE_CLUSTERED | (n_leaves << 8) |
+                                    ((uint32_t)(clusters_off + (int)leaf_index * RT_CLUSTER_QUADS) << 16));
+            q1.v[3] = 0.0f;
+            shadow_items.push_back(q0);
+            shadow_items.push_back(q1);
+        }
     }
     b.shadow_items_off = (int)s->image.size();
     b.n_shadow_items = (int)(shadow_items.size() / 2);

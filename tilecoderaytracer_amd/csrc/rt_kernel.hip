@@ -350,16 +350,36 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
     *best_idx_out = best_idx;
 }
 
-/* wavefront-wide min / max of a per-lane value; call only where all 64 lanes are active */
+/* Wavefront-wide min / max of a per-lane value with DPP (no LDS traffic): four
+ * butterfly steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror,
+ * row mirror), then the four row results are read out as scalars.  Call only
+ * where all 64 lanes are active. */
+template <int kCtrl> __device__ __forceinline__ float dpp_f(const float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kCtrl, 0xF, 0xF, false));
+}
+#define RT_DPP_XOR1 0xB1          /* quad_perm:[1,0,3,2] */
+#define RT_DPP_XOR2 0x4E          /* quad_perm:[2,3,0,1] */
+#define RT_DPP_HALF_MIRROR 0x141  /* row_half_mirror     */
+#define RT_DPP_MIRROR 0x140       /* row_mirror          */
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
-    return v;
+    v = fminf(v, dpp_f<RT_DPP_XOR1>(v));
+    v = fminf(v, dpp_f<RT_DPP_XOR2>(v));
+    v = fminf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
+    v = fminf(v, dpp_f<RT_DPP_MIRROR>(v));
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
+    v = fmaxf(v, dpp_f<RT_DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<RT_DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<RT_DPP_MIRROR>(v));
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 /* inShade + inShadeCollisionDetection, src/RayTracer.cpp:709-771: any non-light
@@ -388,11 +408,14 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
     st_wave(st, ST_WAVE_SHADOW);
 
     const float inf = __builtin_huge_valf();
-    float lox = fminf(wave_min(active ? o.x : inf), light.x), hix = fmaxf(wave_max(active ? o.x : -inf), light.x);
-    float loy = fminf(wave_min(active ? o.y : inf), light.y), hiy = fmaxf(wave_max(active ? o.y : -inf), light.y);
-    float loz = fminf(wave_min(active ? o.z : inf), light.z), hiz = fmaxf(wave_max(active ? o.z : -inf), light.z);
-    const float fuzz = 4.0e-3f * ((hix - lox) + (hiy - loy) + (hiz - loz)) + 1.0e-4f;
-    lox -= fuzz; loy -= fuzz; loz -= fuzz; hix += fuzz; hiy += fuzz; hiz += fuzz;
+    float lox = -inf, loy = -inf, loz = -inf, hix = inf, hiy = inf, hiz = inf;
+    if (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) {      /* with a handful of items the bundle box is not worth computing */
+        lox = fminf(wave_min(active ? o.x : inf), light.x); hix = fmaxf(wave_max(active ? o.x : -inf), light.x);
+        loy = fminf(wave_min(active ? o.y : inf), light.y); hiy = fmaxf(wave_max(active ? o.y : -inf), light.y);
+        loz = fminf(wave_min(active ? o.z : inf), light.z); hiz = fmaxf(wave_max(active ? o.z : -inf), light.z);
+        const float fuzz = 4.0e-3f * ((hix - lox) + (hiy - loy) + (hiz - loz)) + 1.0e-4f;
+        lox -= fuzz; loy -= fuzz; loz -= fuzz; hix += fuzz; hiy += fuzz; hiz += fuzz;
+    }
 
     const int lane = (int)(threadIdx.x & 63u);
     const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
@@ -417,15 +440,21 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, !blocked);
                 sphere_distance(g[0], o, d, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
-            } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a leaf of a clustered run */
+            } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves of a clustered run */
+                const int n_leaves = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
-                const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
-                if (wave_any(lane_needs)) {
-                    const int n = (int)((bits >> 8) & 255u);
+                if (!wave_any(!blocked && box_needed(i0, i1, o, inv, dist_to_light))) continue;   /* per-ray test of the group box */
+                for (int c = 0; c < n_leaves; ++c) {
+                    const float4 c0 = g[c * RT_CLUSTER_QUADS], c1 = g[c * RT_CLUSTER_QUADS + 1];
+                    st_wave(st, ST_WAVE_BOX_TESTS);
+                    const bool lane_needs = !blocked && box_needed(c0, c1, o, inv, dist_to_light);
+                    if (!wave_any(lane_needs)) continue;
+                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
+                    const int n = (int)(__float_as_uint(c0.w) >> 16);
 #pragma unroll 2
                     for (int i = 0; i < n; ++i) {
                         st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
-                        sphere_distance(g[i], o, d, &hit, &t);
+                        sphere_distance(m[i], o, d, &hit, &t);
                         blocked = blocked || (hit && t < dist_to_light);
                     }
                 }
@@ -710,7 +739,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
   }   /* next grab */
 }
 
-extern "C" __global__ void __launch_bounds__(512)
+extern "C" __global__ void __launch_bounds__(256, 5)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
                  float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                  float4 *__restrict__ bounce_stack) {

@@ -40,11 +40,11 @@
  *
  * Shadow items.  The shadow scan (src/RayTracer.cpp:709-739) walks a table of
  * ITEMS: one per non-light object of the scan range, except that a clustered
- * sphere run contributes one item per leaf.  2 quads per item:
+ * sphere run contributes one item per GROUP of leaves.  2 quads per item:
  *   {box lo.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
  *   {box hi.xyz, bits(quad offset of the plane's full 5-quad record)}
  * kind = RT_KIND_SPHERE / _INFINITE_PLANE / _FINITE_PLANE, RT_KIND_SPHERE_CLUSTERED
- * for a leaf (count = members), RT_KIND_FINITE_AA + class for an axis-aligned
+ * for a group (count = its leaves, geometry offset = its first leaf record), RT_KIND_FINITE_AA + class for an axis-aligned
  * rectangle (geometry offset = its AA test record).  The box (inflated on the
  * host) contains the object; an infinite plane's box is all of space.  The
  * wavefront tests 64 item boxes at once, one per lane (rt_kernel.hip, in_shade).
@@ -85,6 +85,8 @@
 #define RT_MAX_LDS_BYTES  (160 * 1024)
 
 #define RT_TILE_STATS 6          /* counting build: words per wavefront tile {cycles, sphere tests, box tests, scans, start, end (100 MHz clock)} */
+
+#define RT_SHADOW_CULL_MIN_ITEMS 8   /* below this many shadow items the wavefront skips the bundle-box cull */
 
 #define RT_STACK_ENTRY_BYTES 16   /* {local.rgb, bits(object index | texsel << 16)} per bounce level per lane */
 
