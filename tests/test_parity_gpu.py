@@ -261,3 +261,104 @@ def test_host_executable_writes_the_reference_log(oracle, tmp_path):
     got_lines = out.read_bytes().split(b"\n")
     want_lines = want.read_bytes().split(b"\n")
     assert got_lines[:7] == want_lines[:7] and got_lines[9:] == want_lines[9:]   # only the two timing lines vary
+
+
+# ------------------------------------------------ stress for the exact culls
+def _adversarial(scene, seed):
+    """Geometry chosen to sit on the edges of the conservative culls: tiny and
+    huge spheres, spheres far from the camera, skewed (non-orthogonal) finite
+    planes, boxes (axis-aligned rectangles), coincident surfaces (distance
+    ties), lights inside clusters, a partial shadow range."""
+    rng = np.random.RandomState(seed)
+    f = lambda x: float(np.float32(x))
+    lights = [((f(rng.uniform(-30, 30)), f(rng.uniform(0, 60)), f(rng.uniform(3, 20))), f(rng.uniform(.3, 1))) for _ in range(2)]
+    for pos, inten in lights:
+        i = scene.add_sphere(pos, 0.2)
+        scene.set_light(i)
+        scene.set_intensity(i, inten)
+    n = int(rng.choice([70, 90, 130]))
+    for k in range(n):                      # enough spheres in a row to be clustered
+        r = f(rng.choice([1e-3, 0.05, 0.4, 1.0, 6.0]))
+        c = (f(rng.uniform(-25, 25)), f(rng.uniform(3, 400 if k % 7 == 0 else 60)), f(rng.uniform(0, 8)))
+        i = scene.add_sphere(c, r)
+        scene.set_color(i, [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)][k % 4])
+        if k % 3 == 0:
+            scene.set_reflective(i, f(rng.choice([0.3, 1.0])))
+            scene.set_diffuse(i, f(rng.choice([0.0, 0.6])))
+        if k % 11 == 0:                     # an exact duplicate: equal distances, the lower index must win
+            j = scene.add_sphere(c, r)
+            scene.set_color(j, (1, 1, 0))
+    for k in range(6):                      # skewed finite planes through the axis constructor
+        o = (f(rng.uniform(-10, 10)), f(rng.uniform(5, 40)), f(rng.uniform(0, 6)))
+        nrm = tuple(f(v) for v in rng.uniform(-1, 1, 3))
+        hor = tuple(f(v) for v in rng.uniform(-1, 1, 3))
+        i = scene.add_finite_plane_axes(o, nrm, hor, f(rng.uniform(1, 9)), f(rng.uniform(1, 9)))
+        scene.set_reflective(i, 0.5)
+    for k in range(2):                      # boxes out of three-corner rectangles (axis-aligned class runs)
+        o = np.float32([rng.uniform(-12, 12), rng.uniform(6, 30), 0])
+        dims = np.float32(rng.uniform(0.5, 5, 3))
+        c = [o.copy() for _ in range(8)]
+        c[1][0] += dims[0]; c[2][1] += dims[1]; c[3][2] += dims[2]
+        c[4][0] += dims[0]; c[4][1] += dims[1]; c[5][0] += dims[0]; c[5][2] += dims[2]
+        c[6][1] += dims[1]; c[6][2] += dims[2]; c[7] = o + dims
+        for a, b, d in ((0, 3, 2), (0, 3, 1), (0, 1, 2), (7, 4, 6), (7, 4, 5), (7, 5, 6)):
+            i = scene.add_finite_plane_corners(tuple(map(float, c[a])), tuple(map(float, c[b])), tuple(map(float, c[d])))
+            scene.set_color(i, (0.2, 0.2, 0.0))
+            if k == 1:
+                scene.set_reflective(i, 0.5)
+    i = scene.add_infinite_plane((0, 0, 0), (0, 0, 1), (1, 0, 0))
+    scene.set_checkerboard(i, (1, 1, 1), (0, 0, 0), 3.0, 3.0)
+    scene.set_reflective(i, 0.5)
+    scene.set_diffuse(i, 0.5)
+    i = scene.add_infinite_plane((0, 0, 25), (0, 0, -1), (1, 0, 0))
+    scene.set_reflective(i, 0.4)
+    mode = seed % 3
+    if mode == 0:
+        scene.set_object_indices(0, 1)
+    elif mode == 1:
+        scene.set_object_indices(1, 3)      # partial shadow range: clustering must stay exact (or switch itself off)
+    scene.camera_two_mirrors()
+    return scene
+
+
+@pytest.mark.parametrize("seed", range(20, 32))
+def test_adversarial_scenes(oracle, seed):
+    host = _adversarial(HostScene.empty(), seed)
+    orc = _adversarial(oracle.OracleScene(), seed)
+    assert_same(Renderer(host).render(96, 64, 5), orc.render(96, 64, 5), f"adversarial seed {seed}")
+
+
+@pytest.mark.parametrize("leaf,group", [(0, 8), (4, 2), (8, 4), (16, 8), (32, 16)])
+def test_cluster_parameters_do_not_change_results(oracle, leaf, group):
+    host = _adversarial(HostScene.empty(), 77)
+    r = Renderer(host)
+    r.set_option("cluster_leaf", leaf)
+    r.set_option("cluster_group", group)
+    assert_same(r.render(80, 48, 4), _adversarial(oracle.OracleScene(), 77).render(80, 48, 4), f"leaf {leaf} group {group}")
+
+
+def test_aa_fast_path_can_be_switched_off(oracle):
+    r = Renderer(HostScene.builtin())
+    r.set_option("aa_planes", 0)
+    assert_same(r.render(120, 90, 4), oracle.OracleScene.builtin().render(120, 90, 4), "aa_planes=0")
+
+
+@pytest.mark.parametrize("seed", range(40, 70))
+def test_more_random_scenes(oracle, seed):
+    from scene_gen import build_random
+    kw = dict(n_spheres=int(4 + seed % 9), n_finite=int(seed % 7), n_infinite=int(seed % 3), n_lights=1 + seed % 3,
+              shadows=(seed % 4 != 0))
+    host = build_random(HostScene.empty(), seed, **kw)
+    orc = build_random(oracle.OracleScene(), seed, **kw)
+    assert_same(Renderer(host).render(64, 48, 6), orc.render(64, 48, 6), f"seed {seed}")
+
+
+def test_counting_build_matches_and_counts(oracle):
+    r = Renderer(HostScene.builtin())
+    img, st = r.render_stats(64, 64, 3)
+    assert_same(img, oracle.OracleScene.builtin().render(64, 64, 3), "counting build")
+    orc = oracle.OracleScene.builtin()
+    orc.render(64, 64, 3)
+    c = oracle.OracleScene.counters()
+    assert st["nearest_rays"] == c.nearest_rays          # same rays traced as the reference restatement
+    assert st["shadow_rays"] == c.shadow_rays
