@@ -64,6 +64,8 @@ def parse_args():
                     help="columns of the image the CPU oracle renders (default: sized for ~10-30 CPU-seconds)")
     ap.add_argument("--tile-z", type=int, default=0, help="wavefront tile height override (speed only)")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the gather even at N = 1 (exercises the RCCL path on one GPU)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: gather each frame before rendering the next (no render/gather pipelining)")
     return ap.parse_args()
@@ -155,8 +157,18 @@ def main():
         sys.exit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints its version banner on stdout when NCCL_DEBUG is set (it is, on this pool);
+        # stdout must carry exactly one JSON line, so route fd 1 to stderr until the result is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     scene_name, W, H, depth, cfg_note = WORKLOADS[args.workload]
@@ -170,14 +182,14 @@ def main():
         renderer.set_option("block_threads", args.block_threads)
 
     stream = torch.cuda.current_stream(dev).cuda_stream
-    pipe = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap)
+    pipe = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap, force_gather=args.force_dist)
     x0, x1, strip = pipe.x0, pipe.x1, pipe.strip
     pipe.render = lambda buf: renderer.render_device(W, H, depth, x0, x1, buf.data_ptr(), stream)
     step = pipe.step
 
     def fence():
         pipe.drain()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -193,7 +205,7 @@ def main():
     tm = renderer.timing()
     kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -257,9 +269,14 @@ def main():
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = repr(e)
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

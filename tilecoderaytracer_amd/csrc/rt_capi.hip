@@ -76,6 +76,7 @@ struct rt_scene {
     int tile_z_log2 = 2;          /* 16 columns x 4 rows per wavefront (measured best on MI355X: wide tiles diverge least) */
     int block_threads_opt = 0;    /* 0 = auto */
     int tiles_per_grab_opt = 0;   /* 0 = auto */
+    int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
@@ -589,14 +590,20 @@ int drain_event(rt_scene *s, int i) {
     return RT_OK;
 }
 
-/* workgroup size: the scene tables are the only LDS user (the bounce stack
- * lives in HBM), so a bigger workgroup shares one staged copy among more
- * wavefronts */
-int choose_block(const rt_scene *s, int *block, int *lds_bytes) {
+/* Workgroup size and where the bounce stack goes.  The stack (16 B per level
+ * per thread) shares LDS with the scene tables when the sum stays within
+ * 160 KiB / 5, i.e. five workgroups per CU still fit; otherwise it moves to
+ * HBM and the tables alone decide the occupancy. */
+int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, int *stack_in_lds) {
     const size_t scene_bytes = (size_t)s->base.image_quads * 16;
     if (scene_bytes > RT_MAX_LDS_BYTES) return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
     *block = s->block_threads_opt ? s->block_threads_opt : 256;
-    *lds_bytes = (int)scene_bytes;
+    const double with_stack = (double)scene_bytes + (double)RT_STACK_ENTRY_BYTES * (double)(max_depth + 1) * (double)*block;
+    const bool in_lds = s->stack_opt == 1 || (s->stack_opt == 0 && with_stack <= (double)(RT_MAX_LDS_BYTES / 5));
+    if (in_lds && with_stack > (double)RT_MAX_LDS_BYTES)
+        return fail(RT_ERR_CAPACITY, "stack option: tables + bounce stack exceed 160 KiB LDS");
+    *stack_in_lds = in_lds ? 1 : 0;
+    *lds_bytes = in_lds ? (int)with_stack : (int)scene_bytes;
     return RT_OK;
 }
 
@@ -610,8 +617,8 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if ((double)(x1 - x0) * (double)H * 3.0 > 2.0e9 * 4.0)
         return fail(RT_ERR_INVALID, "strip too large");
 
-    int block = 0, lds_bytes = 0;
-    int rc = choose_block(s, &block, &lds_bytes);
+    int block = 0, lds_bytes = 0, stack_in_lds = 0;
+    int rc = choose_block(s, max_depth, &block, &lds_bytes, &stack_in_lds);
     if (rc) return rc;
 
     RtParams p = s->base;
@@ -624,6 +631,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.sw = cam->screen_width; p.sh = cam->screen_height;
     p.shw = cam->screen_halfwidth; p.shh = cam->screen_halfheight;
     p.W = W; p.H = H; p.x0 = x0; p.x1 = x1; p.max_depth = max_depth;
+    p.stack_in_lds = stack_in_lds;
     p.tile_z_log2 = s->tile_z_log2;
     const int tile_z = 1 << s->tile_z_log2, tile_x = 64 >> s->tile_z_log2;
     const long long tiles_z = ((long long)H + tile_z - 1) / tile_z;
@@ -672,7 +680,8 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     /* bounce stack: one slice per workgroup of the persistent grid */
     {
-        const double need_d = (double)blocks * (double)block * (double)(max_depth + 1) * RT_STACK_ENTRY_BYTES;
+        const double need_d = stack_in_lds ? 16.0
+                                           : (double)blocks * (double)block * (double)(max_depth + 1) * RT_STACK_ENTRY_BYTES;
         if (need_d > 8.0e9)
             return fail(RT_ERR_CAPACITY, "max_depth too large: the bounce stack would exceed 8 GB of HBM");
         const size_t need = (size_t)need_d;
@@ -906,6 +915,11 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         if (value != 0 && (value < 64 || value > 512 || (value % 64) != 0))
             return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or a multiple of 64 up to 512");
         s->block_threads_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "stack")) {
+        if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "stack must be 0 (auto), 1 (LDS) or 2 (HBM)");
+        s->stack_opt = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "tiles_per_grab")) {

@@ -512,10 +512,14 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
     __syncthreads();
 
-    /* this workgroup's slice of the bounce stack in HBM: [level][threadIdx.x],
-     * one 16-byte entry per reflective level per lane, written and read
-     * coalesced (LDS is left to the scene tables: occupancy) */
-    float4 *stack = bounce_stack + (size_t)blockIdx.x * (size_t)(p.max_depth + 1) * blockDim.x;
+    /* Bounce stack, [level][threadIdx.x], one 16-byte entry per reflective level
+     * per lane.  It lives in LDS behind the scene tables when that keeps at
+     * least five workgroups per CU (small scenes, moderate depth); otherwise in
+     * this workgroup's slice of an HBM buffer, written and read coalesced, so
+     * that a large scene table alone decides the occupancy. */
+    float4 *const lds_stack = lds + p.image_quads;
+    float4 *const hbm_stack = bounce_stack + (size_t)blockIdx.x * (size_t)(p.max_depth + 1) * blockDim.x;
+    const bool stack_in_lds = p.stack_in_lds != 0;
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
 
     /* Self-scheduling (the reference's strategy 2, src/RayTracer.cpp:956-992:
@@ -686,7 +690,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 float4 e;
                 e.x = final_color.x; e.y = final_color.y; e.z = final_color.z;
                 e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
-                stack[level * blockDim.x + threadIdx.x] = e;
+                if (stack_in_lds) lds_stack[level * blockDim.x + threadIdx.x] = e;
+                else              hbm_stack[level * blockDim.x + threadIdx.x] = e;
                 top = level + 1;
                 o = P;
                 d = normalize3(reflected);                   /* Ray(point, reflected) */
@@ -702,7 +707,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     /* unwind: final_k = local_k + (rf_k * C_{k+1}) * oc_k, inside-out (:601) */
     for (int k = levels - 1; k >= 0; --k) {
         if (k < top) {
-            const float4 e = stack[k * blockDim.x + threadIdx.x];
+            const float4 e = stack_in_lds ? lds_stack[k * blockDim.x + threadIdx.x] : hbm_stack[k * blockDim.x + threadIdx.x];
             const uint32_t bits = __float_as_uint(e.w);
             const uint32_t info = lds_u32[p.objinfo_off * 4 + (bits & 0xFFFFu)];
             const int mat = (int)(info >> 20);

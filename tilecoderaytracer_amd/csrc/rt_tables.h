@@ -116,6 +116,7 @@ typedef struct RtParams {
     int32_t n_tiles;                     /* total wavefront tiles   */
     int32_t tiles_per_grab;              /* tiles handed out per queue pop               */
     int32_t n_grabs;                     /* ceil(n_tiles / tiles_per_grab): queue length */
+    int32_t stack_in_lds;                /* bounce stack in LDS (behind the tables) instead of HBM */
 } RtParams;
 
 #endif /* RT_TABLES_H_ */

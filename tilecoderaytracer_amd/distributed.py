@@ -47,13 +47,14 @@ class StripPipeline:
     the caller's function that enqueues the kernel writing `buf`.
     """
 
-    def __init__(self, W, H, world, rank, device, render, overlap=True, dtype=torch.float32):
+    def __init__(self, W, H, world, rank, device, render, overlap=True, dtype=torch.float32, force_gather=False):
         self.world, self.rank, self.render, self.overlap = world, rank, render, overlap
+        self.gather = world > 1 or force_gather          # force_gather: run the collective even with one rank
         self.x0, self.x1, self.strip = strip_bounds(W, world, rank)
-        n_buf = 2 if (overlap and world > 1) else 1
+        n_buf = 2 if (overlap and self.gather) else 1
         self.bufs = [torch.empty((self.strip, H, 3), dtype=dtype, device=device) for _ in range(n_buf)]
         self.pending = [None] * n_buf
-        self.full, self.views = (alloc_full(W, H, world, device, dtype) if (world > 1 and rank == 0)
+        self.full, self.views = (alloc_full(W, H, world, device, dtype) if (self.gather and rank == 0)
                                  else (None, None))
         self.k = 0
 
@@ -64,7 +65,7 @@ class StripPipeline:
             self.pending[b].wait()
             self.pending[b] = None
         self.render(self.bufs[b])
-        if self.world > 1:
+        if self.gather:
             if self.overlap:
                 self.pending[b] = gather_strips(self.bufs[b], self.views, dst=0, async_op=True)
             else:
@@ -79,6 +80,6 @@ class StripPipeline:
     def image(self, W):
         """Rank 0: the gathered framebuffer (first W columns); single GPU: the strip."""
         self.drain()
-        if self.world == 1:
+        if not self.gather:
             return self.bufs[(self.k - 1) % len(self.bufs)]
         return self.full[:W] if self.full is not None else None
