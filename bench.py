@@ -64,6 +64,8 @@ def parse_args():
                     help="columns of the image the CPU oracle renders (default: sized for ~10-30 CPU-seconds)")
     ap.add_argument("--tile-z", type=int, default=0, help="wavefront tile height override (speed only)")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="rt_set_option tuning knob (speed only), e.g. --option stack=2")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the gather even at N = 1 (exercises the RCCL path on one GPU)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -180,6 +182,9 @@ def main():
         renderer.set_option("tile_z", args.tile_z)
     if args.block_threads:
         renderer.set_option("block_threads", args.block_threads)
+    for kv in args.option:
+        k, v = kv.split("=")
+        renderer.set_option(k, int(v))
 
     stream = torch.cuda.current_stream(dev).cuda_stream
     pipe = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap, force_gather=args.force_dist)

@@ -75,7 +75,6 @@ struct rt_scene {
     /* options */
     int tile_z_log2 = 2;          /* 16 columns x 4 rows per wavefront (measured best on MI355X: wide tiles diverge least) */
     int block_threads_opt = 0;    /* 0 = auto */
-    int tiles_per_grab_opt = 0;   /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
@@ -659,7 +658,8 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
      * occupancy query; a larger grid would also be correct, its surplus
      * workgroups simply find the queue empty), never more than there are tiles */
     if (!s->d_counters) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters), kEventRing * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters),
+                          (size_t)kEventRing * RT_TILE_QUEUES * RT_QUEUE_STRIDE * sizeof(unsigned int)));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -697,25 +697,12 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
             s->d_stack_bytes = need;
         }
     }
-    /* Tiles per queue pop.  One counter word saturates near 88 pops/us
-     * (MI355X_MICROARCH.md, "dequeue"); tiles of a small scene are cheap enough
-     * to get there (built-in scene: ~110 tiles/us), so they are handed out in
-     * pairs; heavy scenes pop single tiles for the finest balance.  Always keep
-     * at least ~16 pops per resident wavefront. */
-    {
-        const long long waves = blocks * waves_per_block;
-        long long per = s->objects.size() <= 128 ? 2 : 1;
-        per = std::max(1LL, std::min(per, n_tiles / (waves * 16)));
-        if (s->tiles_per_grab_opt > 0) per = s->tiles_per_grab_opt;
-        p.tiles_per_grab = (int)per;
-        p.n_grabs = (int)((n_tiles + per - 1) / per);
-    }
     const int slot = s->ev_next;
     rc = drain_event(s, slot);            /* ring wrapped: account for the old launch first */
     if (rc) return rc;
     s->ev_next = (s->ev_next + 1) % kEventRing;
-    unsigned int *counter = s->d_counters + slot;
-    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
+    unsigned int *counter = s->d_counters + (size_t)slot * RT_TILE_QUEUES * RT_QUEUE_STRIDE;
+    HIP_TRY(hipMemsetAsync(counter, 0, (size_t)RT_TILE_QUEUES * RT_QUEUE_STRIDE * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
     if (d_stats)
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
@@ -920,11 +907,6 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "stack")) {
         if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "stack must be 0 (auto), 1 (LDS) or 2 (HBM)");
         s->stack_opt = value;
-        return RT_OK;
-    }
-    if (!std::strcmp(key, "tiles_per_grab")) {
-        if (value < 0 || value > 1024) return fail(RT_ERR_INVALID, "tiles_per_grab must be in [0, 1024]");
-        s->tiles_per_grab_opt = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "grid_mult")) {

@@ -419,8 +419,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
 
     const int lane = (int)(threadIdx.x & 63u);
     const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
-    V3 inv = mk(0.0f, 0.0f, 0.0f);
-    if (p.n_clusters) inv = approx_inverse(d);
     const float4 *items = lds + p.shadow_items_off;
     for (int base = 0; base < p.n_shadow_items; base += 64) {
         const int mine = min(base + lane, p.n_shadow_items - 1);
@@ -442,6 +440,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 blocked = blocked || (hit && t < dist_to_light);
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves of a clustered run */
                 const int n_leaves = (int)((bits >> 8) & 255u);
+                const V3 inv = approx_inverse(d);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 if (!wave_any(!blocked && box_needed(i0, i1, o, inv, dist_to_light))) continue;   /* per-ray test of the group box */
                 for (int c = 0; c < n_leaves; ++c) {
@@ -523,28 +522,47 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
 
     /* Self-scheduling (the reference's strategy 2, src/RayTracer.cpp:956-992:
-     * a shared queue of pixels; here a queue of wavefront tiles).  The grid is
-     * only as large as the chip can hold; every WAVEFRONT pulls its next tile
-     * from one device-wide counter until the tiles run out, so expensive tiles
-     * (the horizon, mirror balls) cannot pile up on one XCD the way a static
-     * block -> tile map lets them.  All lanes are active here; every wavefront
-     * reaches the exit test, so the grid always drains. */
+     * a shared queue of pixels; here queues of wavefront tiles).  The grid is
+     * only as large as the chip can hold and every WAVEFRONT pulls its next
+     * tile until the tiles run out, so expensive tiles (the horizon, mirror
+     * balls) cannot pile up the way a static block -> tile map lets them.
+     *
+     * XCD-aware: there is one queue per XCD (8 counters on separate cache
+     * lines, 8x less contention than one word).  The image is cut into MACRO
+     * tiles of RT_MACRO_ROWS vertically adjacent wavefront tiles; macro tile m
+     * belongs to queue m mod 8 -- horizontally adjacent macro tiles go to
+     * different XCDs, so costly image regions are dealt evenly -- and a queue
+     * hands its macro tiles out tile by tile.  The vertically adjacent tiles of
+     * a macro tile are therefore rendered at about the same time by wavefronts
+     * of ONE XCD, and their 48-byte column segments merge into whole 64-byte
+     * sectors in that XCD's L2 before they leave for HBM.  A wavefront whose
+     * own queue is empty steals from the other XCDs' queues (placement is a
+     * speed matter only; any XCC_ID value gives the same image).  All lanes are
+     * active here and every wavefront walks all 8 queues to their end, so the
+     * grid always drains. */
     const int lane = threadIdx.x & 63;
     const int tz = 1 << p.tile_z_log2;
-    /* One atomic hands out `tiles_per_grab` tiles (a single counter word
-     * saturates near 88 dequeues/us, which cheap tiles would exceed).  The
-     * tiles of one grab are n_grabs apart, not adjacent, so expensive
-     * neighbourhoods are spread over many wavefronts. */
-    int next_grab = 0;
-    if (lane == 0) next_grab = (int)atomicAdd(tile_counter, 1u);
-  for (;;) {
-    const int grab = __builtin_amdgcn_readfirstlane(next_grab);
-    if (grab >= p.n_grabs) break;
-    /* ask for the following grab now; the answer is only needed after this one is rendered */
-    if (lane == 0) next_grab = (int)atomicAdd(tile_counter, 1u);
-   for (int part = 0; part < p.tiles_per_grab; ++part) {
-    const int wave = part * p.n_grabs + grab;
-    if (wave >= p.n_tiles) break;
+    const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
+    const int macro_rows = (p.tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
+    const int n_macros = macro_rows * p.tiles_x;
+  for (int steal = 0; steal < RT_TILE_QUEUES; ++steal) {
+    const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
+    unsigned int *const head = tile_counter + queue * RT_QUEUE_STRIDE;
+    /* macro tiles queue, queue + 8, queue + 16, ... */
+    const int queue_len = queue < n_macros ? ((n_macros - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
+    int next_pop = 0;
+    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+   for (;;) {
+    const int pop = __builtin_amdgcn_readfirstlane(next_pop);
+    if (pop >= queue_len) break;
+    /* ask for the following tile now; the answer is only needed after this one is rendered */
+    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+    const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
+    const int macro_row = macro / p.tiles_x;
+    const int tile_col = macro - macro_row * p.tiles_x;
+    const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
+    if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
+    const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
     if constexpr (kStats) {
         for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
         t_start = __builtin_amdgcn_s_memtime();
@@ -553,10 +571,6 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 
     /* pixel of this lane: wavefront tiles are tile_x columns by tile_z rows;
      * consecutive lanes walk z, the contiguous axis of pixels[x][z] */
-    /* tiles are numbered row by row (z outer): the tiles of one grab, n_grabs
-     * apart, then lie in different rows of the image */
-    const int tile_row = wave / p.tiles_x;
-    const int tile_col = wave - tile_row * p.tiles_x;
     const int x = p.x0 + tile_col * (64 >> p.tile_z_log2) + (lane >> p.tile_z_log2);
     const int z = tile_row * tz + (lane & (tz - 1));
     const bool inside = (x < p.x1) && (z < p.H);
@@ -587,24 +601,22 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         levels = level + 1;
         /* ---- phase 1 (per lane): nearest hit and the winner's CollisionObject ---- */
         bool shade = false;          /* this lane hit a non-light object and shades it */
-        V3 P = o, N = d, object_color = null_color;
-        float diffuse_factor = 0.0f, specular_factor = 0.0f, reflective_factor = 0.0f;
-        int idx = -1, texsel = 0;
+        V3 P = o, N = d;
+        int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         if (alive) {
             float t;
             nearest_hit<kStats>(p, runs, lds, o, d, &t, &idx, st);
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
                 alive = false;
+                idx = 0;
             } else {
                 const uint32_t info = lds_u32[p.objinfo_off * 4 + idx];
                 const float4 *g = lds + (info & 0xFFFFu);
                 const int kind = (int)((info >> 16) & 3u);
                 const int mat = (int)(info >> 20);
-                const float4 m0 = lds[p.mat_off + mat * RT_MAT_QUADS];
                 const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
                 const uint32_t mbits = __float_as_uint(m1.w);
-                diffuse_factor = m0.w; specular_factor = m1.x; reflective_factor = m1.y;
                 if (kind == RT_KIND_SPHERE) {                /* src/SceneSphere.cpp:118-149 */
                     const float4 s = g[0];
                     P = add3(scale3(d, t), o);
@@ -624,9 +636,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                     N = (dot3(xyz(q0), d) < 0) ? xyz(q0) : xyz(q4);
                     P = add3(ip, scale3(N, (float)1E-3));
                 }
-                object_color = entry_colour(p, lds, m0, mbits, texsel);
                 if (mbits & 1u) {                            /* hit a light: :520-527 */
-                    C = scale3(object_color, m1.z);
+                    const float4 m0 = lds[p.mat_off + mat * RT_MAT_QUADS];
+                    C = scale3(entry_colour(p, lds, m0, mbits, texsel), m1.z);
                     alive = false;
                 } else {
                     shade = true;
@@ -638,10 +650,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
          * Every lane walks the light loop so that the shadow scan can cull scene
          * items for the wavefront as a whole; lanes with nothing to shade carry
          * shade == false through it. ---- */
-        V3 final_color = mk(0.0f, 0.0f, 0.0f);
-        /* CollisionObject ctor, src/SceneObject.h:62-92 */
-        const V3 normal_dir = normalize3(N);                 /* Ray(point, normal) re-normalises */
-        const float n_dot_incoming = dot3(N, d);
+        /* a shading lane accumulates its colour in C (its previous C is dead: it is
+         * overwritten at the end of every level a lane is alive in) */
+        if (shade) C = mk(0.0f, 0.0f, 0.0f);
         if (wave_any(shade)) {
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
@@ -652,19 +663,26 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), st);
                 if (shade && !blocked) {
+                    /* the winner's material, re-read here rather than kept in registers across the shadow scan */
+                    const int mat = (int)(lds_u32[p.objinfo_off * 4 + idx] >> 20);
+                    const float4 m0 = lds[p.mat_off + mat * RT_MAT_QUADS];
+                    const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
+                    const V3 object_color = entry_colour(p, lds, m0, __float_as_uint(m1.w), texsel);
+                    const float diffuse_factor = m0.w, specular_factor = m1.x;
+                    const V3 normal_dir = normalize3(N);     /* CollisionObject ctor: Ray(point, normal) re-normalises, src/SceneObject.h:62 */
                     const V3 light_color = xyz(l1);
                     /* cosineShade, :654-701 */
                     if (diffuse_factor > (float)0) {
                         float cosine_dot_factor = dot3(normal_dir, light_ray);
                         if (cosine_dot_factor > (float)0) {
                             const float factor = cosine_dot_factor * diffuse_factor * l0.w;
-                            final_color.x += factor * object_color.x * light_color.x;
-                            final_color.y += factor * object_color.y * light_color.y;
-                            final_color.z += factor * object_color.z * light_color.z;
+                            C.x += factor * object_color.x * light_color.x;
+                            C.y += factor * object_color.y * light_color.y;
+                            C.z += factor * object_color.z * light_color.z;
                         }
-                        final_color.x = (final_color.x > 1.0f) ? 1.0f : final_color.x;
-                        final_color.y = (final_color.y > 1.0f) ? 1.0f : final_color.y;
-                        final_color.z = (final_color.z > 1.0f) ? 1.0f : final_color.z;
+                        C.x = (C.x > 1.0f) ? 1.0f : C.x;
+                        C.y = (C.y > 1.0f) ? 1.0f : C.y;
+                        C.z = (C.z > 1.0f) ? 1.0f : C.z;
                     }
                     /* specular, :561-588 */
                     const V3 Nn = normalize3(normal_dir);    /* third normalisation, :566-567 */
@@ -675,7 +693,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 #pragma unroll
                         for (int j = 0; j < 19; ++j) pow_factor *= dot;
                         const float spec_factor = pow_factor * specular_factor;
-                        final_color = add3(final_color, scale3(light_color, spec_factor));
+                        C = add3(C, scale3(light_color, spec_factor));
                     }
                 }
             }
@@ -683,12 +701,15 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 
         /* ---- phase 3 (per lane): reflect or finish, :595-604 ---- */
         if (shade) {
+            const int mat = (int)(lds_u32[p.objinfo_off * 4 + idx] >> 20);
+            const float reflective_factor = lds[p.mat_off + mat * RT_MAT_QUADS + 1].y;
+            const float n_dot_incoming = dot3(N, d);         /* src/SceneObject.h:65 */
             if (reflective_factor > (float)0) {
                 const V3 reflected = mk(-2 * N.x * n_dot_incoming + d.x,
                                         -2 * N.y * n_dot_incoming + d.y,
                                         -2 * N.z * n_dot_incoming + d.z);
                 float4 e;
-                e.x = final_color.x; e.y = final_color.y; e.z = final_color.z;
+                e.x = C.x; e.y = C.y; e.z = C.z;
                 e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
                 if (stack_in_lds) lds_stack[level * blockDim.x + threadIdx.x] = e;
                 else              hbm_stack[level * blockDim.x + threadIdx.x] = e;
@@ -698,8 +719,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 /* if the loop ends now the call at max_depth+1 returns NULL_COLOR, :454-455 */
                 C = null_color;
             } else {
-                C = final_color;
-                alive = false;
+                alive = false;                               /* C already holds final_color */
             }
         }
     }
@@ -720,7 +740,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     }
 
     if (inside) {
-        float *dst = out + ((size_t)(x - p.x0) * (size_t)p.H + (size_t)z) * 3;
+        const int sx = tile_col * (64 >> p.tile_z_log2) + (lane >> p.tile_z_log2);   /* x - x0 */
+        const int sz = tile_row * tz + (lane & (tz - 1));
+        float *dst = out + ((size_t)sx * (size_t)p.H + (size_t)sz) * 3;
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
     }
     if constexpr (kStats) {
@@ -733,15 +755,15 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 rec[0] = __builtin_amdgcn_s_memtime() - t_start;
                 rec[4] = t_start_real;                               /* 100 MHz constant clock */
                 rec[5] = __builtin_amdgcn_s_memrealtime();
+                rec[3] = (unsigned long long)my_xcc * 1000ull + (unsigned long long)steal;   /* diagnostic: XCD and steal distance */
             }
             if (st.c[ST_WAVE_SPHERE_TESTS]) atomicAdd(&rec[1], (unsigned long long)st.c[ST_WAVE_SPHERE_TESTS]);
             if (st.c[ST_WAVE_BOX_TESTS]) atomicAdd(&rec[2], (unsigned long long)st.c[ST_WAVE_BOX_TESTS]);
-            if (st.c[ST_WAVE_NEAREST] + st.c[ST_WAVE_SHADOW])
-                atomicAdd(&rec[3], (unsigned long long)(st.c[ST_WAVE_NEAREST] + st.c[ST_WAVE_SHADOW]));
+
         }
     }
-   }  /* next tile of this grab */
-  }   /* next grab */
+   }  /* next tile of this queue */
+  }   /* next queue */
 }
 
 extern "C" __global__ void __launch_bounds__(256, 5)

@@ -86,6 +86,13 @@
 
 #define RT_TILE_STATS 6          /* counting build: words per wavefront tile {cycles, sphere tests, box tests, scans, start, end (100 MHz clock)} */
 
+/* tile queues: one per XCD, heads RT_QUEUE_STRIDE words apart (own cache lines);
+ * a macro tile is RT_MACRO_ROWS vertically adjacent wavefront tiles */
+#define RT_TILE_QUEUES 8
+#define RT_QUEUE_STRIDE 32
+#define RT_MACRO_ROWS 4
+#define RT_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)   /* s_getreg_b32 HW_REG_XCC_ID, bits [3:0] */
+
 #define RT_SHADOW_CULL_MIN_ITEMS 8   /* below this many shadow items the wavefront skips the bundle-box cull */
 
 #define RT_STACK_ENTRY_BYTES 16   /* {local.rgb, bits(object index | texsel << 16)} per bounce level per lane */
@@ -114,8 +121,6 @@ typedef struct RtParams {
     int32_t tiles_z;                     /* wavefront tiles along z */
     int32_t tiles_x;                     /* wavefront tiles along x */
     int32_t n_tiles;                     /* total wavefront tiles   */
-    int32_t tiles_per_grab;              /* tiles handed out per queue pop               */
-    int32_t n_grabs;                     /* ceil(n_tiles / tiles_per_grab): queue length */
     int32_t stack_in_lds;                /* bounce stack in LDS (behind the tables) instead of HBM */
 } RtParams;
 
