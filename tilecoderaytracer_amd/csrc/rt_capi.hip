@@ -77,6 +77,7 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
+    int near_items_opt = 1;       /* nearest scan over the item table with the bundle cull (0 = run lists) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
@@ -250,7 +251,9 @@ int pack_scene(rt_scene *s) {
     std::vector<int> aa_rec_of((size_t)n, -1);       /* their AA test record (quad offset within aa_recs) */
     std::vector<int> aa_cls_of((size_t)n, -1);
     std::vector<char> clustered((size_t)n, 0);
-    std::vector<Quad> shadow_group_items, shadow_items;
+    struct GroupItem { float lo[3], hi[3]; uint32_t leaf_index, n_leaves, cidx_first; bool in_shadow; };
+    std::vector<GroupItem> group_items;
+    std::vector<Quad> shadow_items, near_items;
     std::vector<Quad> aa_recs;
     struct PendingAA { size_t run_pos; bool shadow; int rec_first, cidx_first; };
     std::vector<PendingAA> pending_aa;
@@ -286,14 +289,15 @@ int pack_scene(rt_scene *s) {
                 groups.push_back({{ball[0].lo[0], ball[0].lo[1], ball[0].lo[2],
                                    bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS))}});
                 groups.push_back({{ball[0].hi[0], ball[0].hi[1], ball[0].hi[2], bits_to_float((uint32_t)(l1 - l0))}});
-                if (in_shadow_all) {
-                    /* shadow item for the group: geometry offset = its first leaf record (index into
-                     * the leaf section, made absolute below), count = its leaves */
-                    shadow_group_items.push_back({{ball[0].lo[0], ball[0].lo[1], ball[0].lo[2],
-                                                   bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS))}});
-                    shadow_group_items.push_back({{ball[0].hi[0], ball[0].hi[1], ball[0].hi[2],
-                                                   bits_to_float((uint32_t)(l1 - l0))}});
-                }
+                /* item for the group: geometry offset = its first leaf record (index into the leaf
+                 * section, made absolute below), count = its leaves */
+                GroupItem gi_rec;
+                for (int k = 0; k < 3; ++k) { gi_rec.lo[k] = ball[0].lo[k]; gi_rec.hi[k] = ball[0].hi[k]; }
+                gi_rec.leaf_index = (uint32_t)(clusters.size() / RT_CLUSTER_QUADS);
+                gi_rec.n_leaves = (uint32_t)(l1 - l0);
+                gi_rec.cidx_first = (uint32_t)cidx_first;
+                gi_rec.in_shadow = in_shadow_all;
+                group_items.push_back(gi_rec);
                 for (int l = l0; l < l1; ++l) {
                     const Leaf &L = leaves[(size_t)l];
                     const int member_off = (int)geom.size();
@@ -387,11 +391,18 @@ int pack_scene(rt_scene *s) {
     s->image.insert(s->image.end(), clusters.begin(), clusters.end());
     const int aa_off = (int)s->image.size();
     s->image.insert(s->image.end(), aa_recs.begin(), aa_recs.end());
-    /* shadow items: every non-light object of the scan range in Scene order (clustered
-     * spheres are represented by their leaves, appended after) */
+    /* Scene-index tables of the clustered / class-sorted runs */
+    const int cidx_off = (int)s->image.size();
+    s->image.resize(s->image.size() + (cidx.size() + 3) / 4, Quad{{0, 0, 0, 0}});
+    if (!cidx.empty()) std::memcpy(s->image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
+
+    /* Item tables (rt_tables.h): one item per object that is not part of a clustered run, in
+     * Scene order, then one per group of each clustered run.  `near_items` covers every object,
+     * `shadow_items` the non-light objects of the shadow scan range. */
     {
         const float INF = INFINITY;
-        auto box_item = [&](const double lo[3], const double hi[3], uint32_t bits, uint32_t full_off, bool unbounded) {
+        auto box_item = [&](std::vector<Quad> &out, const double lo[3], const double hi[3], uint32_t bits,
+                            uint32_t word1, bool unbounded) {
             double ext = 0.0, mag = 0.0;
             for (int k = 0; k < 3; ++k) {
                 ext = std::max(ext, hi[k] - lo[k]);
@@ -405,22 +416,22 @@ int pack_scene(rt_scene *s) {
                 q1.v[k] = ok ? std::nextafter((float)(hi[k] + pad), INF) : INF;
             }
             q0.v[3] = bits_to_float(bits);
-            q1.v[3] = bits_to_float(full_off);
-            shadow_items.push_back(q0);
-            shadow_items.push_back(q1);
+            q1.v[3] = bits_to_float(word1);
+            out.push_back(q0);
+            out.push_back(q1);
         };
-        for (int i = sb; i < se; ++i) {
+        auto object_item = [&](std::vector<Quad> &out, int i) {
             const rt_object_desc &o = objs[i];
-            if (o.is_light || clustered[(size_t)i]) continue;
             double lo[3], hi[3];
             const uint32_t full = (uint32_t)geom_off[(size_t)i];
+            const uint32_t word1 = (uint32_t)i | (full << 12);          /* Scene index | full record offset */
             if (o.kind == RT_KIND_SPHERE) {
                 const double r = std::fabs((double)o.radius);
                 for (int k = 0; k < 3; ++k) { lo[k] = (double)o.origin[k] - r; hi[k] = (double)o.origin[k] + r; }
-                box_item(lo, hi, (uint32_t)RT_KIND_SPHERE | (full << 16), full, false);
+                box_item(out, lo, hi, (uint32_t)RT_KIND_SPHERE | (full << 16), word1, false);
             } else if (o.kind == RT_KIND_INFINITE_PLANE) {
                 for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = 0.0; }
-                box_item(lo, hi, (uint32_t)RT_KIND_INFINITE_PLANE | (full << 16), full, true);
+                box_item(out, lo, hi, (uint32_t)RT_KIND_INFINITE_PLANE | (full << 16), word1, true);
             } else {
                 /* The hit region is {p on the plane : 0 <= (p-po).h <= h_dist, 0 <= (p-po).v <= v_dist}
                  * (src/SceneFinitePlane.cpp:117-124).  h and v need be neither orthogonal to each
@@ -455,24 +466,32 @@ int pack_scene(rt_scene *s) {
                 }
                 if (unbounded) { for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = 0.0; } }
                 if (aa_rec_of[(size_t)i] >= 0)
-                    box_item(lo, hi, (uint32_t)(RT_KIND_FINITE_AA + aa_cls_of[(size_t)i]) |
-                                         ((uint32_t)(aa_off + aa_rec_of[(size_t)i]) << 16), full, unbounded);
+                    box_item(out, lo, hi, (uint32_t)(RT_KIND_FINITE_AA + aa_cls_of[(size_t)i]) |
+                                              ((uint32_t)(aa_off + aa_rec_of[(size_t)i]) << 16), word1, unbounded);
                 else
-                    box_item(lo, hi, (uint32_t)RT_KIND_FINITE_PLANE | (full << 16), full, unbounded);
+                    box_item(out, lo, hi, (uint32_t)RT_KIND_FINITE_PLANE | (full << 16), word1, unbounded);
             }
-        }
-        for (size_t k = 0; k + 1 < shadow_group_items.size(); k += 2) {
-            uint32_t leaf_index, n_leaves;
-            std::memcpy(&leaf_index, &shadow_group_items[k].v[3], 4);
-            std::memcpy(&n_leaves, &shadow_group_items[k + 1].v[3], 4);
-            Quad q0 = shadow_group_items[k], q1 = shadow_group_items[k + 1];
-            q0.v[3] = bits_to_float((uint32_t)RT_KIND_SPHERE_CLUSTERED | (n_leaves << 8) |
-                                    ((uint32_t)(clusters_off + (int)leaf_index * RT_CLUSTER_QUADS) << 16));
-            q1.v[3] = 0.0f;
-            shadow_items.push_back(q0);
-            shadow_items.push_back(q1);
-        }
+        };
+        auto group_item = [&](std::vector<Quad> &out, const GroupItem &g) {
+            Quad q0 = {{g.lo[0], g.lo[1], g.lo[2],
+                        bits_to_float((uint32_t)RT_KIND_SPHERE_CLUSTERED | (g.n_leaves << 8) |
+                                      ((uint32_t)(clusters_off + (int)g.leaf_index * RT_CLUSTER_QUADS) << 16))}};
+            Quad q1 = {{g.hi[0], g.hi[1], g.hi[2], bits_to_float((uint32_t)(cidx_off * 4) + g.cidx_first)}};
+            out.push_back(q0);
+            out.push_back(q1);
+        };
+        for (int i = 0; i < n; ++i)
+            if (!clustered[(size_t)i]) object_item(near_items, i);
+        for (const GroupItem &g : group_items) group_item(near_items, g);
+        for (int i = sb; i < se; ++i)
+            if (!objs[i].is_light && !clustered[(size_t)i]) object_item(shadow_items, i);
+        for (const GroupItem &g : group_items)
+            if (g.in_shadow) group_item(shadow_items, g);
     }
+    b.near_items_off = (int)s->image.size();
+    b.n_near_items = (int)(near_items.size() / 2);
+    b.near_items_on = s->near_items_opt;
+    s->image.insert(s->image.end(), near_items.begin(), near_items.end());
     b.shadow_items_off = (int)s->image.size();
     b.n_shadow_items = (int)(shadow_items.size() / 2);
     s->image.insert(s->image.end(), shadow_items.begin(), shadow_items.end());
@@ -492,9 +511,6 @@ int pack_scene(rt_scene *s) {
     b.objinfo_off = (int)s->image.size();
     s->image.resize(s->image.size() + ((size_t)n + 3) / 4, Quad{{0, 0, 0, 0}});
     if (n > 0) std::memcpy(s->image[(size_t)b.objinfo_off].v, objinfo.data(), (size_t)n * 4);
-    const int cidx_off = (int)s->image.size();
-    s->image.resize(s->image.size() + (cidx.size() + 3) / 4, Quad{{0, 0, 0, 0}});
-    if (!cidx.empty()) std::memcpy(s->image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
     for (const Pending &pd : pending) {
         RtRun &run = s->runs[pd.run_pos];
         run.geom_off = groups_off + pd.cluster_first * RT_CLUSTER_QUADS;
@@ -919,6 +935,11 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "grid_mult")) {
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "grid_mult must be in [0, 64]");
         s->grid_mult = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "near_items")) {
+        s->near_items_opt = value != 0;
+        s->base.near_items_on = s->near_items_opt;
         return RT_OK;
     }
     if (!std::strcmp(key, "aa_planes")) {

@@ -257,6 +257,177 @@ __device__ __forceinline__ V3 approx_inverse(const V3 d) {
     return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 }
 
+/* Wavefront-wide min / max of a per-lane value with DPP (no LDS traffic): four
+ * butterfly steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror,
+ * row mirror), then the four row results are read out as scalars.  Call only
+ * where all 64 lanes are active. */
+template <int kCtrl> __device__ __forceinline__ float dpp_f(const float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kCtrl, 0xF, 0xF, false));
+}
+#define RT_DPP_XOR1 0xB1          /* quad_perm:[1,0,3,2] */
+#define RT_DPP_XOR2 0x4E          /* quad_perm:[2,3,0,1] */
+#define RT_DPP_HALF_MIRROR 0x141  /* row_half_mirror     */
+#define RT_DPP_MIRROR 0x140       /* row_mirror          */
+__device__ __forceinline__ float wave_min(float v) {
+    v = fminf(v, dpp_f<RT_DPP_XOR1>(v));
+    v = fminf(v, dpp_f<RT_DPP_XOR2>(v));
+    v = fminf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
+    v = fminf(v, dpp_f<RT_DPP_MIRROR>(v));
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<RT_DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<RT_DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<RT_DPP_MIRROR>(v));
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+/* getCollision (src/RayTracer.cpp:50-89) over the ITEM table with a
+ * wave-cooperative cull -- the nearest-hit counterpart of in_shade() below.
+ *
+ * Must be called by the whole (converged) wavefront; `active` says whether
+ * this lane has a ray.  The wavefront's rays are bounded by a box of origins
+ * [omin, omax] and a box of directions [dmin, dmax] (DPP min/max reductions).
+ * Any point a ray can reach is o + t*d with o in the origin box, d in the
+ * direction box, 0 <= t <= the largest `nearest so far` -- a superset of the
+ * real rays.  LANE i tests ITEM base+i: with [a, b] = (item box) - (origin box),
+ * grown by the same distance-proportional slack as box_needed(), the item is
+ * reachable only if some t satisfies, on every axis k,
+ *      t * dmin_k <= b_k   and   t * dmax_k >= a_k,
+ * which is an interval intersection with wave-uniform coefficients.  One
+ * ballot gives the candidates; only they get the exact per-lane tests.  The
+ * object a ray hits contains the hit point, and so does its (inflated) box, so
+ * no object that can win is ever culled.  A ray with a NaN component hits
+ * nothing in the reference either and may be ignored by the reductions.
+ * Plain items are visited in Scene index order (strict `<` keeps the first of
+ * equal distances, as the reference does); clustered groups come last and
+ * break ties on the Scene index. */
+template <bool kStats>
+__device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, const bool active,
+                                                  const V3 o, const V3 d, float *best_out, int *best_idx_out,
+                                                  Stats<kStats> &st) {
+    float best = 65535.0f;
+    int best_idx = -1;
+    st_lane(st, ST_NEAREST_RAYS, active);
+    st_wave(st, ST_WAVE_NEAREST);
+    const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
+    const int lane = (int)(threadIdx.x & 63u);
+    const float inf = __builtin_huge_valf();
+
+    /* the bundle (a handful of items is not worth bounding it for) */
+    float dminx = -inf, dmaxx = inf, dminy = -inf, dmaxy = inf, dminz = -inf, dmaxz = inf;
+    bool cull = p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
+    if (cull) {
+        dminx = wave_min(active ? d.x : inf); dmaxx = wave_max(active ? d.x : -inf);
+        dminy = wave_min(active ? d.y : inf); dmaxy = wave_max(active ? d.y : -inf);
+        dminz = wave_min(active ? d.z : inf); dmaxz = wave_max(active ? d.z : -inf);
+        /* directions all over the place: the cone is everything, skip the cull */
+        cull = !((dminx < 0.0f && dmaxx > 0.0f) && (dminy < 0.0f && dmaxy > 0.0f) && (dminz < 0.0f && dmaxz > 0.0f));
+    }
+    float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
+    float rnx = 0, rxx = 0, rny = 0, rxy = 0, rnz = 0, rxz = 0;
+    if (cull) {
+        ominx = wave_min(active ? o.x : inf); omaxx = wave_max(active ? o.x : -inf);
+        ominy = wave_min(active ? o.y : inf); omaxy = wave_max(active ? o.y : -inf);
+        ominz = wave_min(active ? o.z : inf); omaxz = wave_max(active ? o.z : -inf);
+        rnx = __builtin_amdgcn_rcpf(dminx); rxx = __builtin_amdgcn_rcpf(dmaxx);
+        rny = __builtin_amdgcn_rcpf(dminy); rxy = __builtin_amdgcn_rcpf(dmaxy);
+        rnz = __builtin_amdgcn_rcpf(dminz); rxz = __builtin_amdgcn_rcpf(dmaxz);
+    }
+    const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
+    const float4 *items = lds + p.near_items_off;
+
+    for (int base = 0; base < p.n_near_items; base += 64) {
+        unsigned long long mask;
+        if (cull) {
+            const int mine = min(base + lane, p.n_near_items - 1);
+            const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
+            float ax = b0.x - omaxx, bx = b1.x - ominx;
+            float ay = b0.y - omaxy, by = b1.y - ominy;
+            float az = b0.z - omaxz, bz = b1.z - ominz;
+            const float far = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) + fmaxf(fabsf(az), fabsf(bz));
+            const float ex = 4.0e-3f * far + 1.0e-4f;
+            ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
+            /* feasible t: [t_lo, t_hi], starting from [0, 65535 (the reference's infinity) + slack] */
+            float t_lo = 0.0f, t_hi = 65600.0f;
+            bool empty = false;
+            /* t*dmin <= b */
+            if (dminx > 0.0f) t_hi = fminf(t_hi, bx * rnx); else if (dminx < 0.0f) t_lo = fmaxf(t_lo, bx * rnx); else empty = empty || (bx < 0.0f);
+            if (dminy > 0.0f) t_hi = fminf(t_hi, by * rny); else if (dminy < 0.0f) t_lo = fmaxf(t_lo, by * rny); else empty = empty || (by < 0.0f);
+            if (dminz > 0.0f) t_hi = fminf(t_hi, bz * rnz); else if (dminz < 0.0f) t_lo = fmaxf(t_lo, bz * rnz); else empty = empty || (bz < 0.0f);
+            /* t*dmax >= a */
+            if (dmaxx > 0.0f) t_lo = fmaxf(t_lo, ax * rxx); else if (dmaxx < 0.0f) t_hi = fminf(t_hi, ax * rxx); else empty = empty || (ax > 0.0f);
+            if (dmaxy > 0.0f) t_lo = fmaxf(t_lo, ay * rxy); else if (dmaxy < 0.0f) t_hi = fminf(t_hi, ay * rxy); else empty = empty || (ay > 0.0f);
+            if (dmaxz > 0.0f) t_lo = fmaxf(t_lo, az * rxz); else if (dmaxz < 0.0f) t_hi = fminf(t_hi, az * rxz); else empty = empty || (az > 0.0f);
+            empty = empty || (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi));
+            mask = __builtin_amdgcn_ballot_w64(base + lane < p.n_near_items && !empty);
+        } else {
+            const int left = p.n_near_items - base;
+            mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        }
+        while (mask != 0ull) {
+            const int item = base + (__ffsll((long long)mask) - 1);
+            mask &= mask - 1ull;
+            const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
+            const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
+            const int kind = (int)(bits & 15u);
+            const float4 *g = lds + (bits >> 16);
+            const int idx = (int)(bits1 & 4095u);
+            bool hit; float t;
+            if (kind == RT_KIND_SPHERE) {
+                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, active);
+                sphere_distance(g[0], o, d, &hit, &t);
+                if (hit && t < best) { best = t; best_idx = idx; }
+            } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves; bits1 = its Scene-index table */
+                const int n_leaves = (int)((bits >> 8) & 255u);
+                const V3 inv = approx_inverse(d);
+                st_wave(st, ST_WAVE_BOX_TESTS);
+                if (!wave_any(active && box_needed(i0, i1, o, inv, best))) continue;
+                for (int c = 0; c < n_leaves; ++c) {
+                    const float4 c0 = g[c * RT_CLUSTER_QUADS], c1 = g[c * RT_CLUSTER_QUADS + 1];
+                    st_wave(st, ST_WAVE_BOX_TESTS);
+                    const bool lane_needs = active && box_needed(c0, c1, o, inv, best);
+                    if (!wave_any(lane_needs)) continue;
+                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
+                    const int n = (int)(__float_as_uint(c0.w) >> 16);
+                    const uint32_t *ids = lds_u32 + bits1 + __float_as_uint(c1.w);
+#pragma unroll 2
+                    for (int i = 0; i < n; ++i) {
+                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+                        sphere_distance(m[i], o, d, &hit, &t);
+                        if (wave_any(hit)) {
+                            const int member = (int)ids[i];
+                            if (hit && (t < best || (t == best && member < best_idx))) { best = t; best_idx = member; }
+                        }
+                    }
+                }
+            } else if (kind == RT_KIND_INFINITE_PLANE) {
+                st_wave(st, ST_WAVE_PLANE_TESTS);
+                infinite_plane_distance(g[0], o, d, best, &hit, &t);
+                if (hit && t < best) { best = t; best_idx = idx; }
+            } else if (kind >= RT_KIND_FINITE_AA && finite_rays) {
+                st_wave(st, ST_WAVE_PLANE_TESTS);
+                const int cls = kind - RT_KIND_FINITE_AA;
+                aa_rectangle_distance(g[0], g[1], aa_permute(o, cls), aa_permute(d, cls), best, &hit, &t);
+                if (hit && t < best) { best = t; best_idx = idx; }
+            } else {                                             /* finite plane, general routine on the full record */
+                st_wave(st, ST_WAVE_PLANE_TESTS);
+                finite_plane_distance(lds + (bits1 >> 12), o, d, best, &hit, &t);
+                if (hit && t < best) { best = t; best_idx = idx; }
+            }
+        }
+    }
+    *best_out = best;
+    *best_idx_out = active ? best_idx : -1;
+}
+
 /* getCollision, src/RayTracer.cpp:50-89: first strictly-smaller distance in
  * Scene index order wins; "infinity" is 65535. */
 template <bool kStats>
@@ -350,38 +521,6 @@ __device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__re
     *best_idx_out = best_idx;
 }
 
-/* Wavefront-wide min / max of a per-lane value with DPP (no LDS traffic): four
- * butterfly steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror,
- * row mirror), then the four row results are read out as scalars.  Call only
- * where all 64 lanes are active. */
-template <int kCtrl> __device__ __forceinline__ float dpp_f(const float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kCtrl, 0xF, 0xF, false));
-}
-#define RT_DPP_XOR1 0xB1          /* quad_perm:[1,0,3,2] */
-#define RT_DPP_XOR2 0x4E          /* quad_perm:[2,3,0,1] */
-#define RT_DPP_HALF_MIRROR 0x141  /* row_half_mirror     */
-#define RT_DPP_MIRROR 0x140       /* row_mirror          */
-__device__ __forceinline__ float wave_min(float v) {
-    v = fminf(v, dpp_f<RT_DPP_XOR1>(v));
-    v = fminf(v, dpp_f<RT_DPP_XOR2>(v));
-    v = fminf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
-    v = fminf(v, dpp_f<RT_DPP_MIRROR>(v));
-    const int i = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
-    return fminf(fminf(r0, r1), fminf(r2, r3));
-}
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_f<RT_DPP_XOR1>(v));
-    v = fmaxf(v, dpp_f<RT_DPP_XOR2>(v));
-    v = fmaxf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp_f<RT_DPP_MIRROR>(v));
-    const int i = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-
 /* inShade + inShadeCollisionDetection, src/RayTracer.cpp:709-771: any non-light
  * object of the scan range with distance < dist_to_light blocks the light.
  *
@@ -468,7 +607,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 blocked = blocked || (hit && t < dist_to_light);
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                finite_plane_distance(lds + __float_as_uint(i1.w), o, d, dist_to_light, &hit, &t);
+                finite_plane_distance(lds + (__float_as_uint(i1.w) >> 12), o, d, dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
             }
         }
@@ -603,9 +742,13 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         bool shade = false;          /* this lane hit a non-light object and shades it */
         V3 P = o, N = d;
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
-        if (alive) {
-            float t;
+        float t = 0.0f;
+        if (p.near_items_on) {
+            nearest_hit_items<kStats>(p, lds, alive, o, d, &t, &idx, st);    /* whole wavefront, converged */
+        } else if (alive) {
             nearest_hit<kStats>(p, runs, lds, o, d, &t, &idx, st);
+        }
+        if (alive) {
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
                 alive = false;

@@ -42,12 +42,16 @@
  * ITEMS: one per non-light object of the scan range, except that a clustered
  * sphere run contributes one item per GROUP of leaves.  2 quads per item:
  *   {box lo.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
- *   {box hi.xyz, bits(quad offset of the plane's full 5-quad record)}
+ *   {box hi.xyz, bits(Scene index | quad offset of the plane's full 5-quad record << 12)}
+ *   (for a group of a clustered run the second word is the u32 index of the
+ *    run's Scene-index table instead)
  * kind = RT_KIND_SPHERE / _INFINITE_PLANE / _FINITE_PLANE, RT_KIND_SPHERE_CLUSTERED
  * for a group (count = its leaves, geometry offset = its first leaf record), RT_KIND_FINITE_AA + class for an axis-aligned
  * rectangle (geometry offset = its AA test record).  The box (inflated on the
  * host) contains the object; an infinite plane's box is all of space.  The
  * wavefront tests 64 item boxes at once, one per lane (rt_kernel.hip, in_shade).
+ * The nearest-hit scan has the same kind of table over ALL objects, lights
+ * included (nearest_hit_items).
  *
  * The object list is additionally described as RUNS of consecutive objects of
  * one kind and one light flag (an int4 each, kept in global memory and read
@@ -93,6 +97,7 @@
 #define RT_MACRO_ROWS 4
 #define RT_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)   /* s_getreg_b32 HW_REG_XCC_ID, bits [3:0] */
 
+#define RT_NEAR_CULL_MIN_ITEMS 8     /* below this many items the nearest scan skips the bundle cull */
 #define RT_SHADOW_CULL_MIN_ITEMS 8   /* below this many shadow items the wavefront skips the bundle-box cull */
 
 #define RT_STACK_ENTRY_BYTES 16   /* {local.rgb, bits(object index | texsel << 16)} per bounce level per lane */
@@ -113,6 +118,7 @@ typedef struct RtParams {
     /* tables */
     int32_t n_runs, n_lights;
     int32_t n_shadow_items, shadow_items_off;            /* shadow item table (quads), see below */
+    int32_t n_near_items, near_items_off, near_items_on; /* nearest-hit item table; on = use it         */
     int32_t n_clusters;                                  /* leaves of clustered sphere runs       */
     int32_t image_quads;                 /* quads staged into LDS */
     int32_t lights_off, mat_off, tex_off, objinfo_off;   /* quad offsets */
