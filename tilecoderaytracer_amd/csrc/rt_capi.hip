@@ -20,12 +20,12 @@
 #include "rt_tables.h"
 
 extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__restrict__ image,
-                                            const RtRun *__restrict__ runs, float *__restrict__ out,
+                                            float *__restrict__ out,
                                             unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack);
 
 extern "C" __global__ void rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image,
-                                                  const RtRun *__restrict__ runs, float *__restrict__ out,
+                                                  float *__restrict__ out,
                                                   unsigned int *__restrict__ tile_counter,
                                                   float4 *__restrict__ bounce_stack,
                                                   unsigned long long *__restrict__ stats_out);
@@ -65,10 +65,9 @@ struct rt_scene {
     float null_color[3] = {0.75f, 0.75f, 0.75f};
     /* packed tables (host copies) */
     std::vector<Quad> image;
-    std::vector<RtRun> runs;
     RtParams base{};              /* table offsets filled at create */
     /* device copies */
-    void *d_image = nullptr, *d_runs = nullptr;
+    void *d_image = nullptr;
     /* scratch framebuffer for rt_render (host destination) */
     void *d_fb = nullptr;
     size_t d_fb_bytes = 0;
@@ -77,7 +76,6 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
-    int near_items_opt = 1;       /* nearest scan over the item table with the bundle cull (0 = run lists) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
@@ -181,7 +179,7 @@ int pack_scene(rt_scene *s) {
     const rt_object_desc *objs = s->objects.data();
     const int sb = s->shadow_begin, se = s->shadow_end;
 
-    std::vector<Quad> geom, lights, mats, texs, clusters, groups;
+    std::vector<Quad> geom, lights, mats, texs, clusters;
     std::vector<uint32_t> objinfo((size_t)n, 0u), cidx;
     std::vector<int> geom_off((size_t)n, 0), mat_of((size_t)n, 0);
     std::map<std::vector<uint32_t>, int> mat_index;
@@ -242,11 +240,8 @@ int pack_scene(rt_scene *s) {
         }
     };
 
-    s->runs.clear();
     s->n_clusters = 0;
     /* Cluster/idx offsets are patched once the section bases are known. */
-    struct Pending { size_t run_pos; bool shadow; int cluster_first, cidx_first; };
-    std::vector<Pending> pending;
     std::vector<int> aa_all;                         /* axis-aligned finite planes (Scene indices) */
     std::vector<int> aa_rec_of((size_t)n, -1);       /* their AA test record (quad offset within aa_recs) */
     std::vector<int> aa_cls_of((size_t)n, -1);
@@ -255,8 +250,6 @@ int pack_scene(rt_scene *s) {
     std::vector<GroupItem> group_items;
     std::vector<Quad> shadow_items, near_items;
     std::vector<Quad> aa_recs;
-    struct PendingAA { size_t run_pos; bool shadow; int rec_first, cidx_first; };
-    std::vector<PendingAA> pending_aa;
 
     for (const Span &sp : spans) {
         const int first = sp.first, last = sp.first + sp.count;             /* [first, last) */
@@ -277,7 +270,6 @@ int pack_scene(rt_scene *s) {
              * consecutive leaves form a group with its own bounding ball */
             const int G = std::max(1, s->cluster_group);
             const int n_groups = ((int)leaves.size() + G - 1) / G;
-            const int group_first = (int)(groups.size() / RT_CLUSTER_QUADS);
             const int cidx_first = (int)cidx.size();
             for (int gi = 0; gi < n_groups; ++gi) {
                 const int l0 = gi * G, l1 = std::min((int)leaves.size(), l0 + G);
@@ -285,10 +277,6 @@ int pack_scene(rt_scene *s) {
                 for (int l = l0; l < l1; ++l) all.insert(all.end(), leaves[(size_t)l].members.begin(), leaves[(size_t)l].members.end());
                 std::vector<Leaf> ball;
                 make_leaf(objs, all, ball);
-                /* leaf table offset is relative to the leaf section; patched to absolute below */
-                groups.push_back({{ball[0].lo[0], ball[0].lo[1], ball[0].lo[2],
-                                   bits_to_float((uint32_t)(clusters.size() / RT_CLUSTER_QUADS))}});
-                groups.push_back({{ball[0].hi[0], ball[0].hi[1], ball[0].hi[2], bits_to_float((uint32_t)(l1 - l0))}});
                 /* item for the group: geometry offset = its first leaf record (index into the leaf
                  * section, made absolute below), count = its leaves */
                 GroupItem gi_rec;
@@ -309,8 +297,6 @@ int pack_scene(rt_scene *s) {
                 }
             }
             s->n_clusters += (int)leaves.size();
-            pending.push_back(Pending{s->runs.size(), false, group_first, cidx_first});
-            s->runs.push_back(RtRun{RT_KIND_SPHERE_CLUSTERED, n_groups, 0, 0});
         } else if (sp.kind == RT_KIND_FINITE_PLANE && s->aa_planes) {
             /* axis-aligned members leave the in-order run for the class-sorted tables built below */
             for (int i = first; i < last; ++i) emit_geometry(i);
@@ -326,58 +312,24 @@ int pack_scene(rt_scene *s) {
                 }
                 if (aa) {
                     for (int k = i; k < j; ++k) aa_all.push_back(k);
-                } else {
-                    s->runs.push_back(RtRun{sp.kind, j - i, i, geom_off[(size_t)i]});
                 }
                 i = j;
             }
         } else {
             for (int i = first; i < last; ++i) emit_geometry(i);
-            s->runs.push_back(RtRun{sp.kind, sp.count, first, geom_off[(size_t)first]});
         }
         if (geom.size() > RT_MAX_GEOM_QUADS) return fail(RT_ERR_CAPACITY, "geometry table too large");
     }
-    /* merge adjacent plain runs of the same kind (a light flag change does not matter for the nearest scan) */
-    {
-        std::vector<RtRun> merged;
-        std::vector<size_t> remap(s->runs.size());
-        for (size_t r = 0; r < s->runs.size(); ++r) {
-            const RtRun &cur = s->runs[r];
-            if (!merged.empty() && cur.kind != RT_KIND_SPHERE_CLUSTERED && merged.back().kind == cur.kind &&
-                merged.back().first + merged.back().count == cur.first) {
-                merged.back().count += cur.count;
-            } else {
-                merged.push_back(cur);
-            }
-            remap[r] = merged.size() - 1;
-        }
-        for (Pending &pd : pending) if (!pd.shadow) pd.run_pos = remap[pd.run_pos];
-        s->runs.swap(merged);
+    /* axis-aligned rectangles: their two-quad test records (rt_tables.h) */
+    for (int i : aa_all) {
+        float sn, sh, sv; int ka, kb;
+        const int cls = aa_class(objs[i], &sn, &sh, &sv, &ka, &kb);
+        const rt_object_desc &o = objs[i];
+        aa_rec_of[(size_t)i] = (int)aa_recs.size();
+        aa_cls_of[(size_t)i] = cls;
+        aa_recs.push_back({{o.distance_to_origin, sn, sh, sv}});
+        aa_recs.push_back({{o.plane_origin[ka], o.plane_origin[kb], o.h_distance, o.v_distance}});
     }
-    /* axis-aligned rectangles: one run per class, appended after every in-order run */
-    auto emit_aa = [&](const std::vector<int> &ids, bool shadow) {
-        for (int cls = 0; cls < 6; ++cls) {
-            const int rec_first = (int)(aa_recs.size() / RT_AA_QUADS), cidx_first = (int)cidx.size();
-            int count = 0;
-            for (int i : ids) {
-                float sn, sh, sv; int ka, kb;
-                if (aa_class(objs[i], &sn, &sh, &sv, &ka, &kb) != cls) continue;
-                const rt_object_desc &o = objs[i];
-                aa_rec_of[(size_t)i] = (int)aa_recs.size();
-                aa_cls_of[(size_t)i] = cls;
-                aa_recs.push_back({{o.distance_to_origin, sn, sh, sv}});
-                aa_recs.push_back({{o.plane_origin[ka], o.plane_origin[kb], o.h_distance, o.v_distance}});
-                cidx.push_back((uint32_t)i);
-                ++count;
-            }
-            if (!count) continue;
-            std::vector<RtRun> &list = s->runs;
-            (void)shadow;
-            pending_aa.push_back(PendingAA{list.size(), shadow, rec_first, cidx_first});
-            list.push_back(RtRun{RT_KIND_FINITE_AA + cls, count, 0, 0});
-        }
-    };
-    emit_aa(aa_all, false);
     for (int i = 0; i < n; ++i)
         objinfo[(size_t)i] = (uint32_t)geom_off[(size_t)i] | ((uint32_t)objs[i].kind << 16) |
                              ((uint32_t)mat_of[(size_t)i] << 20);
@@ -490,18 +442,10 @@ int pack_scene(rt_scene *s) {
     }
     b.near_items_off = (int)s->image.size();
     b.n_near_items = (int)(near_items.size() / 2);
-    b.near_items_on = s->near_items_opt;
     s->image.insert(s->image.end(), near_items.begin(), near_items.end());
     b.shadow_items_off = (int)s->image.size();
     b.n_shadow_items = (int)(shadow_items.size() / 2);
     s->image.insert(s->image.end(), shadow_items.begin(), shadow_items.end());
-    const int groups_off = (int)s->image.size();
-    for (size_t k = 0; k < groups.size(); k += RT_CLUSTER_QUADS) {      /* leaf index -> absolute quad offset */
-        uint32_t leaf_index;
-        std::memcpy(&leaf_index, &groups[k].v[3], 4);
-        groups[k].v[3] = bits_to_float((uint32_t)(clusters_off + (int)leaf_index * RT_CLUSTER_QUADS));
-    }
-    s->image.insert(s->image.end(), groups.begin(), groups.end());
     b.lights_off = (int)s->image.size();
     s->image.insert(s->image.end(), lights.begin(), lights.end());
     b.mat_off = (int)s->image.size();
@@ -511,19 +455,8 @@ int pack_scene(rt_scene *s) {
     b.objinfo_off = (int)s->image.size();
     s->image.resize(s->image.size() + ((size_t)n + 3) / 4, Quad{{0, 0, 0, 0}});
     if (n > 0) std::memcpy(s->image[(size_t)b.objinfo_off].v, objinfo.data(), (size_t)n * 4);
-    for (const Pending &pd : pending) {
-        RtRun &run = s->runs[pd.run_pos];
-        run.geom_off = groups_off + pd.cluster_first * RT_CLUSTER_QUADS;
-        run.first = cidx_off * 4 + pd.cidx_first;          /* u32 index of the run's member-index table */
-    }
-    for (const PendingAA &pa : pending_aa) {
-        RtRun &run = s->runs[pa.run_pos];
-        run.geom_off = aa_off + pa.rec_first * RT_AA_QUADS;
-        run.first = cidx_off * 4 + pa.cidx_first;
-    }
     if (s->image.empty()) s->image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
     b.image_quads = (int)s->image.size();
-    b.n_runs = (int)s->runs.size();
     b.n_clusters = s->n_clusters;
     b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
     for (int c = 0; c < 3; ++c) b.null_color[c] = s->null_color[c];
@@ -560,17 +493,13 @@ int adopt_desc(const rt_scene_desc *desc, rt_scene *s) {
 int upload_scene(rt_scene *s) {
     HIP_TRY(hipSetDevice(s->device));
     if (s->d_image) { HIP_TRY(hipFree(s->d_image)); s->d_image = nullptr; }
-    if (s->d_runs) { HIP_TRY(hipFree(s->d_runs)); s->d_runs = nullptr; }
     hipEvent_t t0, t1;
     HIP_TRY(hipEventCreate(&t0));
     HIP_TRY(hipEventCreate(&t1));
     HIP_TRY(hipEventRecord(t0, nullptr));
     const size_t image_bytes = s->image.size() * sizeof(Quad);
     HIP_TRY(hipMalloc(&s->d_image, image_bytes));
-    HIP_TRY(hipMalloc(&s->d_runs, (s->runs.size() + 1) * sizeof(RtRun)));
     HIP_TRY(hipMemcpy(s->d_image, s->image.data(), image_bytes, hipMemcpyHostToDevice));
-    if (!s->runs.empty())
-        HIP_TRY(hipMemcpy(s->d_runs, s->runs.data(), s->runs.size() * sizeof(RtRun), hipMemcpyHostToDevice));
     HIP_TRY(hipEventRecord(t1, nullptr));
     HIP_TRY(hipEventSynchronize(t1));
     float ms = 0.f;
@@ -729,13 +658,11 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if (d_stats)
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
                            stream, p, reinterpret_cast<const float4 *>(s->d_image),
-                           reinterpret_cast<const RtRun *>(s->d_runs), d_out, counter,
-                           reinterpret_cast<float4 *>(s->d_stack), d_stats);
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats);
     else
         hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
-                           reinterpret_cast<const RtRun *>(s->d_runs), d_out, counter,
-                           reinterpret_cast<float4 *>(s->d_stack));
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
     s->ev[slot].pending = true;
@@ -789,7 +716,6 @@ int rt_scene_destroy(rt_scene *s) {
     if (s->ev_ready)
         for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].stop); }
     if (s->d_image) (void)hipFree(s->d_image);
-    if (s->d_runs) (void)hipFree(s->d_runs);
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_stack) (void)hipFree(s->d_stack);
@@ -935,11 +861,6 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "grid_mult")) {
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "grid_mult must be in [0, 64]");
         s->grid_mult = value;
-        return RT_OK;
-    }
-    if (!std::strcmp(key, "near_items")) {
-        s->near_items_opt = value != 0;
-        s->base.near_items_on = s->near_items_opt;
         return RT_OK;
     }
     if (!std::strcmp(key, "aa_planes")) {

@@ -18,9 +18,11 @@
  *    (src/RayTracer.cpp:601) is flattened: a forward loop over bounce levels
  *    pushes {local_k, object} on a per-lane stack (16 B per level), a backward loop
  *    combines inside-out, so the association order is the reference's.
- *  - The object list is walked as runs of one primitive kind (rt_tables.h) in
- *    Scene index order; the loop counters are wave-uniform, the tables are read
- *    from LDS with the same address in every lane (a broadcast, no conflicts).
+ *  - The object list is walked as a table of ITEMS (rt_tables.h) in Scene
+ *    index order; the item counter is wave-uniform and the records are read
+ *    from LDS with the same address in every lane (a broadcast).  Before that,
+ *    the wavefront culls the table cooperatively: lane i tests item i's box
+ *    against a bound of all 64 rays, one ballot yields the candidates.
  *
  * Arithmetic contract: IEEE-754 binary32, no FMA contraction
  * (-ffp-contract=off and the pragma below), correctly rounded '/' and sqrtf
@@ -428,99 +430,6 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
     *best_idx_out = active ? best_idx : -1;
 }
 
-/* getCollision, src/RayTracer.cpp:50-89: first strictly-smaller distance in
- * Scene index order wins; "infinity" is 65535. */
-template <bool kStats>
-__device__ __forceinline__ void nearest_hit(const RtParams &p, const RtRun *__restrict__ runs,
-                                            const float4 *lds, const V3 o, const V3 d,
-                                            float *best_out, int *best_idx_out, Stats<kStats> &st) {
-    float best = 65535.0f;
-    int best_idx = -1;
-    st_lane(st, ST_NEAREST_RAYS, true);
-    st_wave(st, ST_WAVE_NEAREST);
-    for (int r = 0; r < p.n_runs; ++r) {
-        const RtRun run = runs[r];
-        const float4 *g = lds + run.geom_off;
-        if (run.kind == RT_KIND_SPHERE) {
-#pragma unroll 2
-            for (int i = 0; i < run.count; ++i) {
-                bool hit; float t;
-                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, true); sphere_distance(g[i], o, d, &hit, &t);
-                if (hit && t < best) { best = t; best_idx = run.first + i; }
-            }
-        } else if (run.kind == RT_KIND_SPHERE_CLUSTERED) {
-            /* leaves in any order: ties go to the lower Scene index, which is
-             * what the in-order scan with a strict `<` yields */
-            const uint32_t *cidx = reinterpret_cast<const uint32_t *>(lds) + run.first;
-            const V3 inv = approx_inverse(d);
-            for (int gi = 0; gi < run.count; ++gi) {
-                /* a hit that enters beyond the nearest distance so far cannot win */
-                const float4 g0 = g[gi * RT_CLUSTER_QUADS], g1 = g[gi * RT_CLUSTER_QUADS + 1];
-                st_wave(st, ST_WAVE_BOX_TESTS);
-                if (!wave_any(box_needed(g0, g1, o, inv, best))) continue;
-                const float4 *leaves = lds + __float_as_uint(g0.w);
-                const int n_leaves = (int)__float_as_uint(g1.w);
-                for (int c = 0; c < n_leaves; ++c) {
-                    const float4 c0 = leaves[c * RT_CLUSTER_QUADS], c1 = leaves[c * RT_CLUSTER_QUADS + 1];
-                    st_wave(st, ST_WAVE_BOX_TESTS);
-                    const bool lane_needs = box_needed(c0, c1, o, inv, best);
-                    if (!wave_any(lane_needs)) continue;
-                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
-                    const int n = (int)(__float_as_uint(c0.w) >> 16);
-                    const uint32_t *ids = cidx + __float_as_uint(c1.w);
-#pragma unroll 2
-                    for (int i = 0; i < n; ++i) {
-                        bool hit; float t;
-                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs); sphere_distance(m[i], o, d, &hit, &t);
-                        if (wave_any(hit)) {
-                            const int idx = (int)ids[i];
-                            if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
-                        }
-                    }
-                }
-            }
-        } else if (run.kind == RT_KIND_INFINITE_PLANE) {
-            for (int i = 0; i < run.count; ++i) {
-                bool hit; float t;
-                st_wave(st, ST_WAVE_PLANE_TESTS); infinite_plane_distance(g[i * RT_PLANE_QUADS], o, d, best, &hit, &t);
-                if (hit && t < best) { best = t; best_idx = run.first + i; }
-            }
-        } else if (run.kind >= RT_KIND_FINITE_AA) {
-            /* class-sorted, hence out of Scene order: ties go to the lower Scene index */
-            const uint32_t *ids = reinterpret_cast<const uint32_t *>(lds) + run.first;
-            if (wave_any(!ray_is_finite(o, d))) {
-                for (int i = 0; i < run.count; ++i) {                       /* general routine on the full record */
-                    const int idx = (int)ids[i];
-                    const float4 *full = lds + (reinterpret_cast<const uint32_t *>(lds)[p.objinfo_off * 4 + idx] & 0xFFFFu);
-                    bool hit; float t;
-                    st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(full, o, d, best, &hit, &t);
-                    if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
-                }
-            } else {
-                const V3 op = aa_permute(o, run.kind - RT_KIND_FINITE_AA), dp = aa_permute(d, run.kind - RT_KIND_FINITE_AA);
-#pragma unroll 2
-                for (int i = 0; i < run.count; ++i) {
-                    bool hit; float t;
-                    st_wave(st, ST_WAVE_PLANE_TESTS); aa_rectangle_distance(g[2 * i], g[2 * i + 1], op, dp, best, &hit, &t);
-                    if (wave_any(hit)) {
-                        const int idx = (int)ids[i];
-                        if (hit && (t < best || (t == best && idx < best_idx))) { best = t; best_idx = idx; }
-                    }
-                }
-            }
-        } else {
-#pragma unroll 2
-            for (int i = 0; i < run.count; ++i) {
-                bool hit; float t;
-                st_wave(st, ST_WAVE_PLANE_TESTS); finite_plane_distance(g + i * RT_PLANE_QUADS, o, d, best, &hit, &t);
-                if (hit && t < best) { best = t; best_idx = run.first + i; }
-            }
-        }
-    }
-    *best_out = best;
-    *best_idx_out = best_idx;
-}
-
 /* inShade + inShadeCollisionDetection, src/RayTracer.cpp:709-771: any non-light
  * object of the scan range with distance < dist_to_light blocks the light.
  *
@@ -638,7 +547,6 @@ __device__ __forceinline__ V3 entry_colour(const RtParams &p, const float4 *lds,
 
 template <bool kStats>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
-                                            const RtRun *__restrict__ runs,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack,
                                             unsigned long long *__restrict__ stats_out) {
@@ -743,11 +651,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         V3 P = o, N = d;
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
-        if (p.near_items_on) {
-            nearest_hit_items<kStats>(p, lds, alive, o, d, &t, &idx, st);    /* whole wavefront, converged */
-        } else if (alive) {
-            nearest_hit<kStats>(p, runs, lds, o, d, &t, &idx, st);
-        }
+        nearest_hit_items<kStats>(p, lds, alive, o, d, &t, &idx, st);        /* whole wavefront, converged */
         if (alive) {
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
@@ -910,16 +814,15 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 }
 
 extern "C" __global__ void __launch_bounds__(256, 5)
-rt_render_kernel(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
-                 float *__restrict__ out, unsigned int *__restrict__ tile_counter,
-                 float4 *__restrict__ bounce_stack) {
-    render_body<false>(p, image, runs, out, tile_counter, bounce_stack, nullptr);
+rt_render_kernel(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+                 unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack) {
+    render_body<false>(p, image, out, tile_counter, bounce_stack, nullptr);
 }
 
 /* the counting build: same arithmetic and control flow plus work counters */
 extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, const RtRun *__restrict__ runs,
-                       float *__restrict__ out, unsigned int *__restrict__ tile_counter,
-                       float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out) {
-    render_body<true>(p, image, runs, out, tile_counter, bounce_stack, stats_out);
+rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                       unsigned long long *__restrict__ stats_out) {
+    render_body<true>(p, image, out, tile_counter, bounce_stack, stats_out);
 }
