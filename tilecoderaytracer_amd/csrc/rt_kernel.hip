@@ -57,10 +57,25 @@ __device__ __forceinline__ V3 normalize3(const V3 v) {
     return mk(v.x / length, v.y / length, v.z / length);
 }
 
+/* vector3d::normalize of a vector that is usually already of unit length (the
+ * reference re-normalises normals it has just normalised, src/SceneObject.h:62,
+ * src/RayTracer.cpp:566-567).  When x*x + y*y + z*z rounds to exactly 1.0f the
+ * reference computes sqrtf(1.0f) = 1.0f and v / 1.0f = v, so if that holds in
+ * every active lane the wavefront skips the square root and the divides; the
+ * result is the reference's either way. */
+__device__ __forceinline__ V3 renormalize3(const V3 v);
+
 /* Wave-level "does any active lane need this": a uniform (scalar) branch, so
  * the guarded block costs no exec-mask bookkeeping; lanes that do not need it
  * run it anyway and discard the result. */
 __device__ __forceinline__ bool wave_any(const bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
+__device__ __forceinline__ V3 renormalize3(const V3 v) {
+    const float s = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (!wave_any(s != 1.0f)) return v;
+    const float length = sqrtf(s);
+    return mk(v.x / length, v.y / length, v.z / length);
+}
 
 /* Work counters of the diagnostic ("counting") build, rt_render_stats().  In
  * the production kernel kStats is false and every use folds away. */
@@ -716,7 +731,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                     const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
                     const V3 object_color = entry_colour(p, lds, m0, __float_as_uint(m1.w), texsel);
                     const float diffuse_factor = m0.w, specular_factor = m1.x;
-                    const V3 normal_dir = normalize3(N);     /* CollisionObject ctor: Ray(point, normal) re-normalises, src/SceneObject.h:62 */
+                    const V3 normal_dir = renormalize3(N);   /* CollisionObject ctor: Ray(point, normal) re-normalises, src/SceneObject.h:62 */
                     const V3 light_color = xyz(l1);
                     /* cosineShade, :654-701 */
                     if (diffuse_factor > (float)0) {
@@ -732,7 +747,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                         C.z = (C.z > 1.0f) ? 1.0f : C.z;
                     }
                     /* specular, :561-588 */
-                    const V3 Nn = normalize3(normal_dir);    /* third normalisation, :566-567 */
+                    const V3 Nn = renormalize3(normal_dir);  /* third normalisation, :566-567 */
                     const V3 R = sub3(light_ray, scale3(Nn, 2.0f * dot3(light_ray, Nn)));
                     const float dot = dot3(d, R);
                     if (dot > (float)0) {
