@@ -328,8 +328,8 @@ __device__ __forceinline__ float wave_max(float v) {
  * break ties on the Scene index. */
 template <bool kStats>
 __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, const bool active,
-                                                  const V3 o, const V3 d, float *best_out, int *best_idx_out,
-                                                  Stats<kStats> &st) {
+                                                  const V3 o, const V3 d, const bool same_origin,
+                                                  float *best_out, int *best_idx_out, Stats<kStats> &st) {
     float best = 65535.0f;
     int best_idx = -1;
     st_lane(st, ST_NEAREST_RAYS, active);
@@ -351,9 +351,13 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
     float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
     float rnx = 0, rxx = 0, rny = 0, rxy = 0, rnz = 0, rxz = 0;
     if (cull) {
-        ominx = wave_min(active ? o.x : inf); omaxx = wave_max(active ? o.x : -inf);
-        ominy = wave_min(active ? o.y : inf); omaxy = wave_max(active ? o.y : -inf);
-        ominz = wave_min(active ? o.z : inf); omaxz = wave_max(active ? o.z : -inf);
+        if (same_origin) {                     /* primary rays: every lane starts at the eye */
+            ominx = omaxx = o.x; ominy = omaxy = o.y; ominz = omaxz = o.z;
+        } else {
+            ominx = wave_min(active ? o.x : inf); omaxx = wave_max(active ? o.x : -inf);
+            ominy = wave_min(active ? o.y : inf); omaxy = wave_max(active ? o.y : -inf);
+            ominz = wave_min(active ? o.z : inf); omaxz = wave_max(active ? o.z : -inf);
+        }
         rnx = __builtin_amdgcn_rcpf(dminx); rxx = __builtin_amdgcn_rcpf(dmaxx);
         rny = __builtin_amdgcn_rcpf(dminy); rxy = __builtin_amdgcn_rcpf(dmaxy);
         rnz = __builtin_amdgcn_rcpf(dminz); rxz = __builtin_amdgcn_rcpf(dmaxz);
@@ -464,7 +468,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
 template <bool kStats>
 __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
-                                         Stats<kStats> &st) {
+                                         const V3 origins_lo, const V3 origins_hi, Stats<kStats> &st) {
     bool blocked = !active;
     if (p.n_shadow_items == 0) return false;
     st_lane(st, ST_SHADOW_RAYS, active);
@@ -473,9 +477,10 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
     const float inf = __builtin_huge_valf();
     float lox = -inf, loy = -inf, loz = -inf, hix = inf, hiy = inf, hiz = inf;
     if (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) {      /* with a handful of items the bundle box is not worth computing */
-        lox = fminf(wave_min(active ? o.x : inf), light.x); hix = fmaxf(wave_max(active ? o.x : -inf), light.x);
-        loy = fminf(wave_min(active ? o.y : inf), light.y); hiy = fmaxf(wave_max(active ? o.y : -inf), light.y);
-        loz = fminf(wave_min(active ? o.z : inf), light.z); hiz = fmaxf(wave_max(active ? o.z : -inf), light.z);
+        /* [origins_lo, origins_hi] bounds the origins of all active lanes (computed once per bounce level) */
+        lox = fminf(origins_lo.x, light.x); hix = fmaxf(origins_hi.x, light.x);
+        loy = fminf(origins_lo.y, light.y); hiy = fmaxf(origins_hi.y, light.y);
+        loz = fminf(origins_lo.z, light.z); hiz = fmaxf(origins_hi.z, light.z);
         const float fuzz = 4.0e-3f * ((hix - lox) + (hiy - loy) + (hiz - loz)) + 1.0e-4f;
         lox -= fuzz; loy -= fuzz; loz -= fuzz; hix += fuzz; hiy += fuzz; hiz += fuzz;
     }
@@ -666,7 +671,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         V3 P = o, N = d;
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
-        nearest_hit_items<kStats>(p, lds, alive, o, d, &t, &idx, st);        /* whole wavefront, converged */
+        nearest_hit_items<kStats>(p, lds, alive, o, d, level == 0, &t, &idx, st);   /* whole wavefront, converged */
         if (alive) {
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
@@ -716,6 +721,13 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
          * overwritten at the end of every level a lane is alive in) */
         if (shade) C = mk(0.0f, 0.0f, 0.0f);
         if (wave_any(shade)) {
+            /* box of the shading points, shared by every light's shadow scan */
+            V3 plo = mk(0.0f, 0.0f, 0.0f), phi = plo;
+            if (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) {
+                const float inf = __builtin_huge_valf();
+                plo = mk(wave_min(shade ? P.x : inf), wave_min(shade ? P.y : inf), wave_min(shade ? P.z : inf));
+                phi = mk(wave_max(shade ? P.x : -inf), wave_max(shade ? P.y : -inf), wave_max(shade ? P.z : -inf));
+            }
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
@@ -723,7 +735,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 const V3 dir = sub3(xyz(l0), P);
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
-                const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), st);
+                const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), plo, phi, st);
                 if (shade && !blocked) {
                     /* the winner's material, re-read here rather than kept in registers across the shadow scan */
                     const int mat = (int)(lds_u32[p.objinfo_off * 4 + idx] >> 20);
