@@ -328,7 +328,8 @@ __device__ __forceinline__ float wave_max(float v) {
  * break ties on the Scene index. */
 template <bool kStats>
 __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, const bool active,
-                                                  const V3 o, const V3 d, const bool same_origin,
+                                                  const V3 o, const V3 d, const bool have_origin_box,
+                                                  const V3 origins_lo, const V3 origins_hi,
                                                   float *best_out, int *best_idx_out, Stats<kStats> &st) {
     float best = 65535.0f;
     int best_idx = -1;
@@ -351,8 +352,9 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
     float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
     float rnx = 0, rxx = 0, rny = 0, rxy = 0, rnz = 0, rxz = 0;
     if (cull) {
-        if (same_origin) {                     /* primary rays: every lane starts at the eye */
-            ominx = omaxx = o.x; ominy = omaxy = o.y; ominz = omaxz = o.z;
+        if (have_origin_box) {                 /* the eye for primary rays, else the previous level's shading points */
+            ominx = origins_lo.x; ominy = origins_lo.y; ominz = origins_lo.z;
+            omaxx = origins_hi.x; omaxy = origins_hi.y; omaxz = origins_hi.z;
         } else {
             ominx = wave_min(active ? o.x : inf); omaxx = wave_max(active ? o.x : -inf);
             ominy = wave_min(active ? o.y : inf); omaxy = wave_max(active ? o.y : -inf);
@@ -663,6 +665,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     bool alive = inside;
 
     /* calculatePixel, src/RayTracer.cpp:448-638, levels 0..max_depth */
+    /* a box around the origins of the rays about to be traced: the eye at level 0,
+     * afterwards the shading points of the level before (reflected rays start there) */
+    V3 box_lo = o, box_hi = o;
+    bool have_box = true;
     for (int level = 0; level <= p.max_depth; ++level) {
         if (__ballot(alive) == 0ull) break;
         levels = level + 1;
@@ -671,7 +677,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         V3 P = o, N = d;
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
-        nearest_hit_items<kStats>(p, lds, alive, o, d, level == 0, &t, &idx, st);   /* whole wavefront, converged */
+        nearest_hit_items<kStats>(p, lds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);   /* whole wavefront, converged */
         if (alive) {
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
@@ -722,12 +728,13 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         if (shade) C = mk(0.0f, 0.0f, 0.0f);
         if (wave_any(shade)) {
             /* box of the shading points, shared by every light's shadow scan */
-            V3 plo = mk(0.0f, 0.0f, 0.0f), phi = plo;
-            if (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) {
+            have_box = p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
+            if (have_box) {
                 const float inf = __builtin_huge_valf();
-                plo = mk(wave_min(shade ? P.x : inf), wave_min(shade ? P.y : inf), wave_min(shade ? P.z : inf));
-                phi = mk(wave_max(shade ? P.x : -inf), wave_max(shade ? P.y : -inf), wave_max(shade ? P.z : -inf));
+                box_lo = mk(wave_min(shade ? P.x : inf), wave_min(shade ? P.y : inf), wave_min(shade ? P.z : inf));
+                box_hi = mk(wave_max(shade ? P.x : -inf), wave_max(shade ? P.y : -inf), wave_max(shade ? P.z : -inf));
             }
+            const V3 plo = box_lo, phi = box_hi;
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
