@@ -76,7 +76,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(LIB_DIR, "libtcrt.so")
+    """lib/libtcrt.so next to this package, unless TCRT_LIBRARY names another build of it."""
+    return os.environ.get("TCRT_LIBRARY") or os.path.join(LIB_DIR, "libtcrt.so")
 
 
 def load_library():

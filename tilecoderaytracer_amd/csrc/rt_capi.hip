@@ -76,6 +76,7 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
+    int leaf_items_opt = 1;       /* clustered runs appear in the item tables leaf by leaf (0: group by group) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
@@ -248,6 +249,8 @@ int pack_scene(rt_scene *s) {
     std::vector<char> clustered((size_t)n, 0);
     struct GroupItem { float lo[3], hi[3]; uint32_t leaf_index, n_leaves, cidx_first; bool in_shadow; };
     std::vector<GroupItem> group_items;
+    struct LeafItem { float lo[3], hi[3]; uint32_t member_off, count, cidx_slot; bool in_shadow; };
+    std::vector<LeafItem> leaf_items;
     std::vector<Quad> shadow_items, near_items;
     std::vector<Quad> aa_recs;
 
@@ -294,6 +297,13 @@ int pack_scene(rt_scene *s) {
                     clusters.push_back({{L.lo[0], L.lo[1], L.lo[2],
                                          bits_to_float((uint32_t)member_off | ((uint32_t)L.members.size() << 16))}});
                     clusters.push_back({{L.hi[0], L.hi[1], L.hi[2], bits_to_float((uint32_t)slot)}});
+                    LeafItem li;
+                    for (int k = 0; k < 3; ++k) { li.lo[k] = L.lo[k]; li.hi[k] = L.hi[k]; }
+                    li.member_off = (uint32_t)member_off;
+                    li.count = (uint32_t)L.members.size();
+                    li.cidx_slot = (uint32_t)(cidx_first + slot);
+                    li.in_shadow = in_shadow_all;
+                    leaf_items.push_back(li);
                 }
             }
             s->n_clusters += (int)leaves.size();
@@ -434,11 +444,27 @@ int pack_scene(rt_scene *s) {
         };
         for (int i = 0; i < n; ++i)
             if (!clustered[(size_t)i]) object_item(near_items, i);
-        for (const GroupItem &g : group_items) group_item(near_items, g);
+        auto leaf_item = [&](std::vector<Quad> &out, const LeafItem &l) {
+            Quad q0 = {{l.lo[0], l.lo[1], l.lo[2],
+                        bits_to_float((uint32_t)RT_KIND_SPHERE_LEAF | (l.count << 8) | (l.member_off << 16))}};
+            Quad q1 = {{l.hi[0], l.hi[1], l.hi[2], bits_to_float((uint32_t)(cidx_off * 4) + l.cidx_slot)}};
+            out.push_back(q0);
+            out.push_back(q1);
+        };
+        if (s->leaf_items_opt) {
+            for (const LeafItem &l : leaf_items) leaf_item(near_items, l);
+        } else {
+            for (const GroupItem &g : group_items) group_item(near_items, g);
+        }
         for (int i = sb; i < se; ++i)
             if (!objs[i].is_light && !clustered[(size_t)i]) object_item(shadow_items, i);
-        for (const GroupItem &g : group_items)
-            if (g.in_shadow) group_item(shadow_items, g);
+        if (s->leaf_items_opt) {
+            for (const LeafItem &l : leaf_items)
+                if (l.in_shadow) leaf_item(shadow_items, l);
+        } else {
+            for (const GroupItem &g : group_items)
+                if (g.in_shadow) group_item(shadow_items, g);
+        }
     }
     b.near_items_off = (int)s->image.size();
     b.n_near_items = (int)(near_items.size() / 2);
@@ -861,6 +887,14 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "grid_mult")) {
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "grid_mult must be in [0, 64]");
         s->grid_mult = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "leaf_items")) {
+        const int old = s->leaf_items_opt;
+        s->leaf_items_opt = value != 0;
+        int rc = pack_scene(s);
+        if (rc == RT_OK) rc = upload_scene(s);
+        if (rc) { s->leaf_items_opt = old; return rc; }
         return RT_OK;
     }
     if (!std::strcmp(key, "aa_planes")) {

@@ -270,6 +270,13 @@ __device__ __forceinline__ bool box_needed(const float4 b0, const float4 b1, con
     return !(miss || behind || beyond);
 }
 
+__device__ __forceinline__ float uniform_f(const float v) {
+#ifdef RT_NO_UNIFORM
+    return v;
+#endif
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 __device__ __forceinline__ V3 approx_inverse(const V3 d) {
     return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 }
@@ -360,9 +367,9 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             ominy = wave_min(active ? o.y : inf); omaxy = wave_max(active ? o.y : -inf);
             ominz = wave_min(active ? o.z : inf); omaxz = wave_max(active ? o.z : -inf);
         }
-        rnx = __builtin_amdgcn_rcpf(dminx); rxx = __builtin_amdgcn_rcpf(dmaxx);
-        rny = __builtin_amdgcn_rcpf(dminy); rxy = __builtin_amdgcn_rcpf(dmaxy);
-        rnz = __builtin_amdgcn_rcpf(dminz); rxz = __builtin_amdgcn_rcpf(dmaxz);
+        rnx = uniform_f(__builtin_amdgcn_rcpf(dminx)); rxx = uniform_f(__builtin_amdgcn_rcpf(dmaxx));
+        rny = uniform_f(__builtin_amdgcn_rcpf(dminy)); rxy = uniform_f(__builtin_amdgcn_rcpf(dmaxy));
+        rnz = uniform_f(__builtin_amdgcn_rcpf(dminz)); rxz = uniform_f(__builtin_amdgcn_rcpf(dmaxz));
     }
     const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
     const float4 *items = lds + p.near_items_off;
@@ -408,6 +415,22 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, active);
                 sphere_distance(g[0], o, d, &hit, &t);
                 if (hit && t < best) { best = t; best_idx = idx; }
+            } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run; bits1 = its members' Scene indices */
+                const int n = (int)((bits >> 8) & 255u);
+                const V3 inv = approx_inverse(d);
+                st_wave(st, ST_WAVE_BOX_TESTS);
+                const bool lane_needs = active && box_needed(i0, i1, o, inv, best);
+                if (!wave_any(lane_needs)) continue;
+                const uint32_t *ids = lds_u32 + bits1;
+#pragma unroll 2
+                for (int i = 0; i < n; ++i) {
+                    st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+                    sphere_distance(g[i], o, d, &hit, &t);
+                    if (wave_any(hit)) {
+                        const int member = (int)ids[i];
+                        if (hit && (t < best || (t == best && member < best_idx))) { best = t; best_idx = member; }
+                    }
+                }
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves; bits1 = its Scene-index table */
                 const int n_leaves = (int)((bits >> 8) & 255u);
                 const V3 inv = approx_inverse(d);
@@ -435,7 +458,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 infinite_plane_distance(g[0], o, d, best, &hit, &t);
                 if (hit && t < best) { best = t; best_idx = idx; }
-            } else if (kind >= RT_KIND_FINITE_AA && finite_rays) {
+            } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 6 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 const int cls = kind - RT_KIND_FINITE_AA;
                 aa_rectangle_distance(g[0], g[1], aa_permute(o, cls), aa_permute(d, cls), best, &hit, &t);
@@ -476,31 +499,56 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
     st_lane(st, ST_SHADOW_RAYS, active);
     st_wave(st, ST_WAVE_SHADOW);
 
-    const float inf = __builtin_huge_valf();
-    float lox = -inf, loy = -inf, loz = -inf, hix = inf, hiy = inf, hiz = inf;
-    if (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) {      /* with a handful of items the bundle box is not worth computing */
-        /* [origins_lo, origins_hi] bounds the origins of all active lanes (computed once per bounce level) */
-        lox = fminf(origins_lo.x, light.x); hix = fmaxf(origins_hi.x, light.x);
-        loy = fminf(origins_lo.y, light.y); hiy = fmaxf(origins_hi.y, light.y);
-        loz = fminf(origins_lo.z, light.z); hiz = fmaxf(origins_hi.z, light.z);
-        const float fuzz = 4.0e-3f * ((hix - lox) + (hiy - loy) + (hiz - loz)) + 1.0e-4f;
-        lox -= fuzz; loy -= fuzz; loz -= fuzz; hix += fuzz; hiy += fuzz; hiz += fuzz;
+    /* The bundle of shadow segments: every origin lies within half-extent e of the
+     * centre c of [origins_lo, origins_hi], and all segments end at the light, so
+     * the point at parameter s of any of them is within (1-s) e of c + s (light - c).
+     * An item can matter only if its box, grown by e (and the rounding slack),
+     * meets that centre segment for some s in [0, 1]: a slab test per item-lane. */
+    const bool cull = p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS;
+    V3 c = mk(0, 0, 0), e = c, sinv = c;     /* e: half-extent plus slack */
+    if (cull) {
+        float grow;
+        c = mk(0.5f * (origins_lo.x + origins_hi.x), 0.5f * (origins_lo.y + origins_hi.y), 0.5f * (origins_lo.z + origins_hi.z));
+        /* half-extent, rounded up so that [c - e, c + e] really covers the origin box */
+        e = mk(fmaxf(origins_hi.x - c.x, c.x - origins_lo.x) * 1.000001f, fmaxf(origins_hi.y - c.y, c.y - origins_lo.y) * 1.000001f,
+               fmaxf(origins_hi.z - c.z, c.z - origins_lo.z) * 1.000001f);
+        const V3 seg = sub3(light, c);
+        sinv = approx_inverse(seg);
+        grow = 4.0e-3f * ((fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z)) + 1.0e-4f;
+        /* all of these are the same in every lane: keep them in scalar registers */
+        c = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
+        e = mk(uniform_f(e.x + grow), uniform_f(e.y + grow), uniform_f(e.z + grow));
+        sinv = mk(uniform_f(sinv.x), uniform_f(sinv.y), uniform_f(sinv.z));
     }
-
     const int lane = (int)(threadIdx.x & 63u);
     const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
     const float4 *items = lds + p.shadow_items_off;
+    (void)light;
     for (int base = 0; base < p.n_shadow_items; base += 64) {
-        const int mine = min(base + lane, p.n_shadow_items - 1);
-        const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
-        const bool apart = (b0.x > hix) || (b1.x < lox) || (b0.y > hiy) || (b1.y < loy) || (b0.z > hiz) || (b1.z < loz);
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(base + lane < p.n_shadow_items && !apart);
+        unsigned long long mask;
+        if (cull) {
+            const int mine = min(base + lane, p.n_shadow_items - 1);
+            const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
+            const float gx = e.x, gy = e.y, gz = e.z;
+            const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
+            const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
+            const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
+            const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            /* every comparison is false on a NaN, which then means "candidate" */
+            const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
+                               (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
+            mask = __builtin_amdgcn_ballot_w64(base + lane < p.n_shadow_items && !apart);
+        } else {
+            const int left = p.n_shadow_items - base;
+            mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        }
         while (mask != 0ull) {
             const int item = base + (__ffsll((long long)mask) - 1);
             mask &= mask - 1ull;
             if (!wave_any(!blocked)) return true;
             const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
-            const uint32_t bits = __float_as_uint(i0.w);
+            const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
             const int kind = (int)(bits & 15u);
             const float4 *g = lds + (bits >> 16);
             bool hit; float t;
@@ -508,6 +556,18 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, !blocked);
                 sphere_distance(g[0], o, d, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
+            } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run */
+                const int n = (int)((bits >> 8) & 255u);
+                const V3 inv = approx_inverse(d);
+                st_wave(st, ST_WAVE_BOX_TESTS);
+                const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
+                if (!wave_any(lane_needs)) continue;
+#pragma unroll 2
+                for (int i = 0; i < n; ++i) {
+                    st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+                    sphere_distance(g[i], o, d, &hit, &t);
+                    blocked = blocked || (hit && t < dist_to_light);
+                }
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves of a clustered run */
                 const int n_leaves = (int)((bits >> 8) & 255u);
                 const V3 inv = approx_inverse(d);
@@ -531,14 +591,14 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 infinite_plane_distance(g[0], o, d, dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
-            } else if (kind >= RT_KIND_FINITE_AA && finite_rays) {
+            } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 6 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 const int cls = kind - RT_KIND_FINITE_AA;
                 aa_rectangle_distance(g[0], g[1], aa_permute(o, cls), aa_permute(d, cls), dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                finite_plane_distance(lds + (__float_as_uint(i1.w) >> 12), o, d, dist_to_light, &hit, &t);
+                finite_plane_distance(lds + (bits1 >> 12), o, d, dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
             }
         }

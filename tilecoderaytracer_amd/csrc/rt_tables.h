@@ -77,6 +77,10 @@
  * kind = 4 + class, class = 2*normal_axis + (horizontal_axis == (normal_axis+1)%3 ? 0 : 1).
  * The full 5-quad record of each plane is kept too (winner record, non-finite rays). */
 #define RT_KIND_FINITE_AA 4
+/* one leaf of a clustered sphere run as an item: count = its members, geometry
+ * offset = its first member sphere, second word = u32 index of its members'
+ * Scene indices */
+#define RT_KIND_SPHERE_LEAF 10
 #define RT_AA_QUADS 2
 
 #define RT_MAX_GEOM_QUADS 65535   /* 16-bit geometry offset in objinfo */
