@@ -144,13 +144,18 @@ int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W,
  *   4 sphere tests issued (wavefronts) 5 plane tests issued (wavefronts)
  *   6 cluster box tests issued (wavefronts)
  *   7 sphere tests the lane itself needed (lanes)
+ *   8, 9, 10 shader cycles wavefronts spent in nearest-hit scans, in shadow
+ *     scans, and on whole tiles (each wavefront counts its own resident time,
+ *     so these are comparable with each other, not with wall time)
+ *   11, 12, 13 the same for the winner's collision record, the light loop
+ *     (shadow scans included) and the reflection step
  * wave_cycles (may be NULL) receives, per wavefront tile in row-major order
  * (tile = tile_row * tiles_x + tile_col), six words {shader cycles the
  * wavefront was resident, sphere tests it issued, box tests it issued, scans
  * it ran, start and end time on the 100 MHz constant clock}, up to
  * n_wave_cycles words.  out_rgb may be NULL.  The reference has no
  * counterpart (its gprof figures are quoted in SURVEY.md section 3.3). */
-#define RT_STATS_COUNT 8
+#define RT_STATS_COUNT 14
 int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                     int max_depth, float *out_rgb, uint64_t *stats, int n_stats,
                     uint64_t *wave_cycles, int n_wave_cycles);

@@ -11,6 +11,9 @@ for name, d in [("builtin", 4), ("grid32", 4), ("grid32-noshadow", 4), ("grid16"
     px = S * S
     print(name, f"{S}x{S} d{d}")
     for k, v in st.items():
+        if k.startswith("cycles"):
+            print(f"   {k:20s} {v:14d}   share of tile cycles: {v / max(st['cycles_tile'], 1):.3f}")
+            continue
         per = v / px if not k.startswith("wave") else v * 64 / px
         print(f"   {k:20s} {v:14d}   per pixel{' (x64 lanes)' if k.startswith('wave') else ''}: {per:10.2f}")
     ws, ls = st["wave_sphere_tests"] * 64, st["lane_sphere_tests"]

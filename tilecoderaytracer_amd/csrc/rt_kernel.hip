@@ -88,6 +88,12 @@ enum {
     ST_WAVE_PLANE_TESTS,    /* wavefronts: plane tests issued                              */
     ST_WAVE_BOX_TESTS,      /* wavefronts: cluster box tests issued                        */
     ST_LANE_SPHERE_TESTS,   /* lanes: sphere tests the lane itself needed                  */
+    ST_CYCLES_NEAREST,      /* shader cycles wavefronts spent inside nearest-hit scans     */
+    ST_CYCLES_SHADOW,       /* ... inside shadow scans                                     */
+    ST_CYCLES_TILE,         /* ... on whole tiles (camera ray to framebuffer store)        */
+    ST_CYCLES_WINNER,       /* ... on the winner's CollisionObject (point, normal, texture) */
+    ST_CYCLES_LIGHTS,       /* ... in the light loop, shadow scans included                 */
+    ST_CYCLES_REFLECT,      /* ... reflecting (phase 3)                                     */
     ST_COUNT
 };
 template <bool kStats> struct Stats { };
@@ -99,6 +105,16 @@ template <> __device__ __forceinline__ void st_wave<true>(Stats<true> &st, int k
     const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
     const int lane = (int)(threadIdx.x & 63u);
     st.c[k] += (lane == __ffsll((long long)m) - 1) ? 1u : 0u;       /* first active lane counts for the wave */
+}
+
+template <bool kStats> __device__ __forceinline__ unsigned long long st_clock() {
+    if constexpr (kStats) return __builtin_amdgcn_s_memtime();
+    return 0ull;
+}
+template <bool kStats> __device__ __forceinline__ void st_cycles(Stats<kStats> &, int, unsigned long long) {}
+template <> __device__ __forceinline__ void st_cycles<true>(Stats<true> &st, int k, unsigned long long since) {
+    const unsigned int dt = (unsigned int)(__builtin_amdgcn_s_memtime() - since);
+    st.c[k] += ((threadIdx.x & 63u) == 0u) ? dt : 0u;
 }
 
 /* SceneSphere::collision reduced to its distance, src/SceneSphere.cpp:50-116.
@@ -292,6 +308,37 @@ template <int kCtrl> __device__ __forceinline__ float dpp_f(const float v) {
 #define RT_DPP_XOR2 0x4E          /* quad_perm:[2,3,0,1] */
 #define RT_DPP_HALF_MIRROR 0x141  /* row_half_mirror     */
 #define RT_DPP_MIRROR 0x140       /* row_mirror          */
+/* Box of a per-lane point over the lanes with `use` set: three minima and three
+ * maxima reduced side by side (the six chains fill each other's DPP wait
+ * states): four butterfly steps inside each row of 16 lanes, then row_bcast
+ * 15 / 31 fold the rows so that lane 63 holds the result.  All 64 lanes must be
+ * active.  v_min/v_max ignore a NaN operand, like fminf/fmaxf. */
+__device__ __forceinline__ void wave_bounds3(const V3 v, const bool use, V3 *lo, V3 *hi) {
+    const float inf = __builtin_huge_valf();
+    float a = use ? v.x : inf, b = use ? v.y : inf, c = use ? v.z : inf;
+    float d = use ? v.x : -inf, e = use ? v.y : -inf, f = use ? v.z : -inf;
+#define RT_DPP_STEP(ctrl)                                                                              \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n v_min_f32_dpp %1, %1, %1 " ctrl "\n v_min_f32_dpp %2, %2, %2 " ctrl "\n" \
+    "v_max_f32_dpp %3, %3, %3 " ctrl "\n v_max_f32_dpp %4, %4, %4 " ctrl "\n v_max_f32_dpp %5, %5, %5 " ctrl "\n"
+    asm volatile("s_nop 1\n"
+                 RT_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 RT_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#undef RT_DPP_STEP
+    *lo = mk(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63)),
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63)),
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63)));
+    *hi = mk(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63)),
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 63)),
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63)));
+}
+
+#ifdef RT_OLD_REDUCTIONS
 __device__ __forceinline__ float wave_min(float v) {
     v = fminf(v, dpp_f<RT_DPP_XOR1>(v));
     v = fminf(v, dpp_f<RT_DPP_XOR2>(v));
@@ -312,6 +359,7 @@ __device__ __forceinline__ float wave_max(float v) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+#endif
 
 /* getCollision (src/RayTracer.cpp:50-89) over the ITEM table with a
  * wave-cooperative cull -- the nearest-hit counterpart of in_shade() below.
@@ -350,9 +398,15 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
     float dminx = -inf, dmaxx = inf, dminy = -inf, dmaxy = inf, dminz = -inf, dmaxz = inf;
     bool cull = p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
     if (cull) {
+#ifdef RT_OLD_REDUCTIONS
         dminx = wave_min(active ? d.x : inf); dmaxx = wave_max(active ? d.x : -inf);
         dminy = wave_min(active ? d.y : inf); dmaxy = wave_max(active ? d.y : -inf);
         dminz = wave_min(active ? d.z : inf); dmaxz = wave_max(active ? d.z : -inf);
+#else
+        V3 dlo, dhi;
+        wave_bounds3(d, active, &dlo, &dhi);
+        dminx = dlo.x; dminy = dlo.y; dminz = dlo.z; dmaxx = dhi.x; dmaxy = dhi.y; dmaxz = dhi.z;
+#endif
         /* directions all over the place: the cone is everything, skip the cull */
         cull = !((dminx < 0.0f && dmaxx > 0.0f) && (dminy < 0.0f && dmaxy > 0.0f) && (dminz < 0.0f && dmaxz > 0.0f));
     }
@@ -363,9 +417,15 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             ominx = origins_lo.x; ominy = origins_lo.y; ominz = origins_lo.z;
             omaxx = origins_hi.x; omaxy = origins_hi.y; omaxz = origins_hi.z;
         } else {
+#ifdef RT_OLD_REDUCTIONS
             ominx = wave_min(active ? o.x : inf); omaxx = wave_max(active ? o.x : -inf);
             ominy = wave_min(active ? o.y : inf); omaxy = wave_max(active ? o.y : -inf);
             ominz = wave_min(active ? o.z : inf); omaxz = wave_max(active ? o.z : -inf);
+#else
+            V3 olo, ohi;
+            wave_bounds3(o, active, &olo, &ohi);
+            ominx = olo.x; ominy = olo.y; ominz = olo.z; omaxx = ohi.x; omaxy = ohi.y; omaxz = ohi.z;
+#endif
         }
         rnx = uniform_f(__builtin_amdgcn_rcpf(dminx)); rxx = uniform_f(__builtin_amdgcn_rcpf(dmaxx));
         rny = uniform_f(__builtin_amdgcn_rcpf(dminy)); rxy = uniform_f(__builtin_amdgcn_rcpf(dmaxy));
@@ -635,6 +695,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     extern __shared__ float4 lds[];
     Stats<kStats> st;
     unsigned long long t_start = 0ull, t_start_real = 0ull;
+    if constexpr (kStats) {
+        for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
+    }
 
     /* stage the scene tables: global -> LDS, once per workgroup */
     for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
@@ -692,8 +755,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
     if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
+    unsigned int tile_sphere0 = 0u, tile_box0 = 0u;
     if constexpr (kStats) {
-        for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
+        tile_sphere0 = st.c[ST_WAVE_SPHERE_TESTS]; tile_box0 = st.c[ST_WAVE_BOX_TESTS];
         t_start = __builtin_amdgcn_s_memtime();
         t_start_real = __builtin_amdgcn_s_memrealtime();
     }
@@ -737,7 +801,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         V3 P = o, N = d;
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
+        const unsigned long long t_scan = st_clock<kStats>();
         nearest_hit_items<kStats>(p, lds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);   /* whole wavefront, converged */
+        st_cycles(st, ST_CYCLES_NEAREST, t_scan);
+        const unsigned long long t_winner = st_clock<kStats>();
         if (alive) {
             if (idx < 0) {                                   /* :507-509 */
                 C = null_color;
@@ -785,14 +852,20 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
          * shade == false through it. ---- */
         /* a shading lane accumulates its colour in C (its previous C is dead: it is
          * overwritten at the end of every level a lane is alive in) */
+        st_cycles(st, ST_CYCLES_WINNER, t_winner);
+        const unsigned long long t_lights = st_clock<kStats>();
         if (shade) C = mk(0.0f, 0.0f, 0.0f);
         if (wave_any(shade)) {
             /* box of the shading points, shared by every light's shadow scan */
             have_box = p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
             if (have_box) {
                 const float inf = __builtin_huge_valf();
+#ifdef RT_OLD_REDUCTIONS
                 box_lo = mk(wave_min(shade ? P.x : inf), wave_min(shade ? P.y : inf), wave_min(shade ? P.z : inf));
                 box_hi = mk(wave_max(shade ? P.x : -inf), wave_max(shade ? P.y : -inf), wave_max(shade ? P.z : -inf));
+#else
+                wave_bounds3(P, shade, &box_lo, &box_hi);
+#endif
             }
             const V3 plo = box_lo, phi = box_hi;
             for (int l = 0; l < p.n_lights; ++l) {
@@ -802,7 +875,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 const V3 dir = sub3(xyz(l0), P);
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
+                const unsigned long long t_shadow = st_clock<kStats>();
                 const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), plo, phi, st);
+                st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
                     /* the winner's material, re-read here rather than kept in registers across the shadow scan */
                     const int mat = (int)(lds_u32[p.objinfo_off * 4 + idx] >> 20);
@@ -841,6 +916,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         }
 
         /* ---- phase 3 (per lane): reflect or finish, :595-604 ---- */
+        st_cycles(st, ST_CYCLES_LIGHTS, t_lights);
+        const unsigned long long t_reflect = st_clock<kStats>();
         if (shade) {
             const int mat = (int)(lds_u32[p.objinfo_off * 4 + idx] >> 20);
             const float reflective_factor = lds[p.mat_off + mat * RT_MAT_QUADS + 1].y;
@@ -863,6 +940,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 alive = false;                               /* C already holds final_color */
             }
         }
+        st_cycles(st, ST_CYCLES_REFLECT, t_reflect);
     }
 
     /* unwind: final_k = local_k + (rf_k * C_{k+1}) * oc_k, inside-out (:601) */
@@ -887,9 +965,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
     }
     if constexpr (kStats) {
-        for (int k = 0; k < ST_COUNT; ++k)
-            if (st.c[k]) atomicAdd(&stats_out[k], (unsigned long long)st.c[k]);
-        /* per wavefront tile: shader cycles spent on it, then its wave-level counters */
+        st_cycles(st, ST_CYCLES_TILE, t_start);
+        /* per wavefront tile: shader cycles spent on it, then its wave-level counters
+         * (the totals are added up once per wavefront, after its last tile) */
         {
             unsigned long long *rec = stats_out + ST_COUNT + (size_t)wave * RT_TILE_STATS;
             if (lane == 0) {
@@ -898,13 +976,17 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 rec[5] = __builtin_amdgcn_s_memrealtime();
                 rec[3] = (unsigned long long)my_xcc * 1000ull + (unsigned long long)steal;   /* diagnostic: XCD and steal distance */
             }
-            if (st.c[ST_WAVE_SPHERE_TESTS]) atomicAdd(&rec[1], (unsigned long long)st.c[ST_WAVE_SPHERE_TESTS]);
-            if (st.c[ST_WAVE_BOX_TESTS]) atomicAdd(&rec[2], (unsigned long long)st.c[ST_WAVE_BOX_TESTS]);
+            if (st.c[ST_WAVE_SPHERE_TESTS] != tile_sphere0) atomicAdd(&rec[1], (unsigned long long)(st.c[ST_WAVE_SPHERE_TESTS] - tile_sphere0));
+            if (st.c[ST_WAVE_BOX_TESTS] != tile_box0) atomicAdd(&rec[2], (unsigned long long)(st.c[ST_WAVE_BOX_TESTS] - tile_box0));
 
         }
     }
    }  /* next tile of this queue */
   }   /* next queue */
+    if constexpr (kStats) {
+        for (int k = 0; k < ST_COUNT; ++k)
+            if (st.c[k]) atomicAdd(&stats_out[k], (unsigned long long)st.c[k]);
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(256, 5)

@@ -96,11 +96,11 @@ extern "C" int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *
         for (int g = 0; g < ngpu; ++g) {
             (void)hipSetDevice(g);
             if (comms[(size_t)g] && rccl.CommDestroy) rccl.CommDestroy(comms[(size_t)g]);
-            if (streams[(size_t)g]) hipStreamDestroy(streams[(size_t)g]);
-            if (d_strip[(size_t)g]) hipFree(d_strip[(size_t)g]);
+            if (streams[(size_t)g]) (void)hipStreamDestroy(streams[(size_t)g]);
+            if (d_strip[(size_t)g]) (void)hipFree(d_strip[(size_t)g]);
             if (scenes[(size_t)g]) rt_scene_destroy(scenes[(size_t)g]);
         }
-        if (d_full) { (void)hipSetDevice(0); hipFree(d_full); }
+        if (d_full) { (void)hipSetDevice(0); (void)hipFree(d_full); }
         if (rccl.handle) dlclose(rccl.handle);
     };
 #define HIP_OR_BAIL(expr)                                                             \

@@ -55,20 +55,22 @@ class Renderer:
                                               C.c_void_p(device_ptr), C.c_void_p(stream)))
 
     STAT_NAMES = ("nearest_rays", "shadow_rays", "wave_nearest_scans", "wave_shadow_scans",
-                  "wave_sphere_tests", "wave_plane_tests", "wave_box_tests", "lane_sphere_tests")
+                  "wave_sphere_tests", "wave_plane_tests", "wave_box_tests", "lane_sphere_tests",
+                  "cycles_nearest", "cycles_shadow", "cycles_tile",
+                  "cycles_winner", "cycles_lights", "cycles_reflect")
 
     def render_stats(self, W, H, max_depth, x0=0, x1=None, wave_cycles=False):
         """Counting build: returns (image, {counter: value}[, per wavefront tile (tiles_z, tiles_x, 6) = cycles, sphere tests, box tests, scans, start, end (100 MHz)])."""
         x1 = W if x1 is None else x1
         out = np.empty((max(x1 - x0, 0), H, 3), dtype=np.float32)
-        st = (C.c_uint64 * 8)()
+        st = (C.c_uint64 * len(self.STAT_NAMES))()
         li = self.launch_info()
         tz = li.tile_z or 4
         tx = 64 // tz
         tiles = ((H + tz - 1) // tz, (x1 - x0 + tx - 1) // tx)      # (tile rows, tile columns), row-major
         cyc = np.zeros(tiles + (6,), dtype=np.uint64)
         capi.check(self._lib.rt_render_stats(self._scene, self._cam, W, H, x0, x1, max_depth,
-                                             out.ctypes.data, st, 8,
+                                             out.ctypes.data, st, len(self.STAT_NAMES),
                                              cyc.ctypes.data if wave_cycles else None, cyc.size if wave_cycles else 0))
         stats = dict(zip(self.STAT_NAMES, [int(v) for v in st]))
         return (out, stats, cyc) if wave_cycles else (out, stats)
