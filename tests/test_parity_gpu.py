@@ -186,6 +186,26 @@ def test_facing_mirrors_depth_400(oracle):
     assert_same(Renderer(host).render(48, 40, 400), orc.render(48, 40, 400), "facing mirrors d400")
 
 
+@pytest.mark.parametrize("width,height", [(3.0, 3.0), (0.3, 7.7), (1.0e-3, 2.5), (1.0e5, 0.75), (2.0 ** -110, 1.0),
+                                          (1.0, 2.0 ** 101), (0.0, 1.0), (-2.0, 3.0)])
+def test_checkerboard_coordinates(oracle, width, height):
+    """Texture_CheckerBoard::getTexturePixel (src/Texture_CheckerBoard.h:31-65) on an
+    infinite plane seen to the horizon: negative and positive coordinates, quotients
+    from < 1 to > 2^20, degenerate cell sizes -- the kernel's short fmodf route and the
+    library route it falls back to must both give the reference's cells."""
+    host, orc = HostScene.empty(), oracle.OracleScene()
+    for s in (host, orc):
+        i = s.add_sphere((2.0, -3.0, 9.0), 0.15)
+        s.set_light(i)
+        g = s.add_infinite_plane((0.3, 0.1, -1.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+        s.set_checkerboard(g, (1.0, 1.0, 1.0), (0.0, 0.0, 0.25), width, height)
+        s.set_reflective(g, 0.25)
+        k = s.add_sphere((0.5, 6.0, 0.5), 1.5)
+        s.set_reflective(k, 1.0)
+        s.set_object_indices(0, 1)
+    assert_same(Renderer(host).render(96, 64, 3), orc.render(96, 64, 3), f"checkerboard {width} x {height}")
+
+
 # ------------------------------------------- full-size (BASELINE.json sizes)
 def test_4096_builtin_depth4_properties(oracle):
     """configs[1] at full size.  (a) (float)(64k)/4096 == (float)k/64, so the

@@ -562,14 +562,14 @@ int drain_event(rt_scene *s, int i) {
 
 /* Workgroup size and where the bounce stack goes.  The stack (16 B per level
  * per thread) shares LDS with the scene tables when the sum stays within
- * 160 KiB / 5, i.e. five workgroups per CU still fit; otherwise it moves to
+ * 160 KiB / 6, i.e. six workgroups per CU still fit; otherwise it moves to
  * HBM and the tables alone decide the occupancy. */
 int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, int *stack_in_lds) {
     const size_t scene_bytes = (size_t)s->base.image_quads * 16;
     if (scene_bytes > RT_MAX_LDS_BYTES) return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
     *block = s->block_threads_opt ? s->block_threads_opt : 256;
     const double with_stack = (double)scene_bytes + (double)RT_STACK_ENTRY_BYTES * (double)(max_depth + 1) * (double)*block;
-    const bool in_lds = s->stack_opt == 1 || (s->stack_opt == 0 && with_stack <= (double)(RT_MAX_LDS_BYTES / 5));
+    const bool in_lds = s->stack_opt == 1 || (s->stack_opt == 0 && with_stack <= (double)(RT_MAX_LDS_BYTES / RT_STACK_LDS_SHARE));
     if (in_lds && with_stack > (double)RT_MAX_LDS_BYTES)
         return fail(RT_ERR_CAPACITY, "stack option: tables + bounce stack exceed 160 KiB LDS");
     *stack_in_lds = in_lds ? 1 : 0;

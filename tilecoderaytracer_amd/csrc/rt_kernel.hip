@@ -381,6 +381,25 @@ __device__ __forceinline__ float wave_max(float v) {
  * Plain items are visited in Scene index order (strict `<` keeps the first of
  * equal distances, as the reference does); clustered groups come last and
  * break ties on the Scene index. */
+/* The bundle cull of nearest_hit_items() asks, per axis, for the t >= 0 with
+ * t dmin <= b and t dmax >= a (dmin, dmax: the bundle's direction range; a, b:
+ * the item box relative to the origin box).  Each inequality bounds t from
+ * below or from above depending on the sign of its direction bound; this
+ * returns, for one axis, the factors that turn b (first pair) and a (second
+ * pair) into that lower / upper bound.  The factor of the bound an inequality
+ * does not give is NaN, which min/max skip.  A zero direction bound gives an
+ * infinite factor: "0 <= b" becomes t <= +-inf (or no bound when b == 0). */
+__device__ __forceinline__ void bound_multipliers(const float dmin, const float dmax, float *lower_b, float *upper_b,
+                                                  float *lower_a, float *upper_a) {
+    const float nan = __builtin_nanf("");
+    const float rmin = __builtin_amdgcn_rcpf(fabsf(dmin)), rmax = __builtin_amdgcn_rcpf(fabsf(dmax));
+    const bool min_negative = dmin < 0.0f, max_positive = dmax > 0.0f;
+    *lower_b = uniform_f(min_negative ? -rmin : nan);
+    *upper_b = uniform_f(min_negative ? nan : rmin);
+    *lower_a = uniform_f(max_positive ? rmax : nan);
+    *upper_a = uniform_f(max_positive ? nan : -rmax);
+}
+
 template <bool kStats>
 __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, const bool active,
                                                   const V3 o, const V3 d, const bool have_origin_box,
@@ -411,7 +430,11 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
         cull = !((dminx < 0.0f && dmaxx > 0.0f) && (dminy < 0.0f && dmaxy > 0.0f) && (dminz < 0.0f && dmaxz > 0.0f));
     }
     float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
+#ifdef RT_BRANCHY_CULL
     float rnx = 0, rxx = 0, rny = 0, rxy = 0, rnz = 0, rxz = 0;
+#else
+    float lax = 0, hax = 0, lbx = 0, hbx = 0, lay = 0, hay = 0, lby = 0, hby = 0, laz = 0, haz = 0, lbz = 0, hbz = 0;
+#endif
     if (cull) {
         if (have_origin_box) {                 /* the eye for primary rays, else the previous level's shading points */
             ominx = origins_lo.x; ominy = origins_lo.y; ominz = origins_lo.z;
@@ -427,12 +450,20 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             ominx = olo.x; ominy = olo.y; ominz = olo.z; omaxx = ohi.x; omaxy = ohi.y; omaxz = ohi.z;
 #endif
         }
+#ifdef RT_BRANCHY_CULL
         rnx = uniform_f(__builtin_amdgcn_rcpf(dminx)); rxx = uniform_f(__builtin_amdgcn_rcpf(dmaxx));
         rny = uniform_f(__builtin_amdgcn_rcpf(dminy)); rxy = uniform_f(__builtin_amdgcn_rcpf(dmaxy));
         rnz = uniform_f(__builtin_amdgcn_rcpf(dminz)); rxz = uniform_f(__builtin_amdgcn_rcpf(dmaxz));
+#else
+        bound_multipliers(dminx, dmaxx, &lax, &hax, &lbx, &hbx);
+        bound_multipliers(dminy, dmaxy, &lay, &hay, &lby, &hby);
+        bound_multipliers(dminz, dmaxz, &laz, &haz, &lbz, &hbz);
+#endif
     }
     const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
     const float4 *items = lds + p.near_items_off;
+    V3 inv = mk(0.0f, 0.0f, 0.0f);           /* 1 / d for the leaf box tests, if the scene has any */
+    if (p.n_clusters > 0) inv = approx_inverse(d);
 
     for (int base = 0; base < p.n_near_items; base += 64) {
         unsigned long long mask;
@@ -446,6 +477,13 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             const float ex = 4.0e-3f * far + 1.0e-4f;
             ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
             /* feasible t: [t_lo, t_hi], starting from [0, 65535 (the reference's infinity) + slack] */
+#ifndef RT_BRANCHY_CULL
+            /* t dmin <= b and t dmax >= a per axis, as lower / upper bounds of t through
+             * the multipliers of bound_multipliers(); a NaN product is no bound */
+            const float t_lo = fmaxf(fmaxf(fmaxf(0.0f, fmaxf(bx * lax, ax * lbx)), fmaxf(by * lay, ay * lby)), fmaxf(bz * laz, az * lbz));
+            const float t_hi = fminf(fminf(fminf(65600.0f, fminf(bx * hax, ax * hbx)), fminf(by * hay, ay * hby)), fminf(bz * haz, az * hbz));
+            const bool empty = (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi)) || (t_hi < -1.0e-6f);
+#else
             float t_lo = 0.0f, t_hi = 65600.0f;
             bool empty = false;
             /* t*dmin <= b */
@@ -457,6 +495,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             if (dmaxy > 0.0f) t_lo = fmaxf(t_lo, ay * rxy); else if (dmaxy < 0.0f) t_hi = fminf(t_hi, ay * rxy); else empty = empty || (ay > 0.0f);
             if (dmaxz > 0.0f) t_lo = fmaxf(t_lo, az * rxz); else if (dmaxz < 0.0f) t_hi = fminf(t_hi, az * rxz); else empty = empty || (az > 0.0f);
             empty = empty || (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi));
+#endif
             mask = __builtin_amdgcn_ballot_w64(base + lane < p.n_near_items && !empty);
         } else {
             const int left = p.n_near_items - base;
@@ -477,7 +516,6 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 if (hit && t < best) { best = t; best_idx = idx; }
             } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run; bits1 = its members' Scene indices */
                 const int n = (int)((bits >> 8) & 255u);
-                const V3 inv = approx_inverse(d);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 const bool lane_needs = active && box_needed(i0, i1, o, inv, best);
                 if (!wave_any(lane_needs)) continue;
@@ -493,7 +531,6 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 }
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves; bits1 = its Scene-index table */
                 const int n_leaves = (int)((bits >> 8) & 255u);
-                const V3 inv = approx_inverse(d);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 if (!wave_any(active && box_needed(i0, i1, o, inv, best))) continue;
                 for (int c = 0; c < n_leaves; ++c) {
@@ -583,7 +620,8 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
     const int lane = (int)(threadIdx.x & 63u);
     const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
     const float4 *items = lds + p.shadow_items_off;
-    (void)light;
+    V3 inv = mk(0.0f, 0.0f, 0.0f);
+    if (p.n_clusters > 0) inv = approx_inverse(d);
     for (int base = 0; base < p.n_shadow_items; base += 64) {
         unsigned long long mask;
         if (cull) {
@@ -618,7 +656,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 blocked = blocked || (hit && t < dist_to_light);
             } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run */
                 const int n = (int)((bits >> 8) & 255u);
-                const V3 inv = approx_inverse(d);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
                 if (!wave_any(lane_needs)) continue;
@@ -630,7 +667,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 }
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves of a clustered run */
                 const int n_leaves = (int)((bits >> 8) & 255u);
-                const V3 inv = approx_inverse(d);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 if (!wave_any(!blocked && box_needed(i0, i1, o, inv, dist_to_light))) continue;   /* per-ray test of the group box */
                 for (int c = 0; c < n_leaves; ++c) {
@@ -668,11 +704,41 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
 
 /* Texture_CheckerBoard::getTexturePixel, src/Texture_CheckerBoard.h:31-65.
  * Returns 1 for the light colour, 2 for the dark colour. */
+/* fmodf(x, y) for 0 <= x < 2^20 y, y a normal number well inside the exponent
+ * range; ry = v_rcp_f32(y) (1 ulp).  The result is the library's, bit for bit:
+ * q = rint(x * ry) is within 3/4 of x / y, so r = x - q y (one fma: exact
+ * product, one rounding) has |r| <= 3/4 y; for x >= y both x and q y are
+ * multiples of ulp(y) and |r| < 2^(ey+1), so r is representable and the fma
+ * returned it exactly, and so is r + y when r < 0.  The unique value in [0, y)
+ * congruent to x is fmodf's.  For x < y fmodf returns x itself. */
+__device__ __forceinline__ float fmod_small_quotient(const float x, const float y, const float ry) {
+    const float q = __builtin_rintf(x * ry);
+    float r = __builtin_fmaf(-q, y, x);
+    r = (r < 0.0f) ? r + y : r;
+    return (x < y) ? x : r;
+}
+
+__device__ __forceinline__ bool fmod_small_quotient_ok(const float x, const float y) {
+    return (y >= 0x1p-100f) && (y <= 0x1p+100f) && (fabsf(x) < 0x1p+20f * y);
+}
+
 __device__ __forceinline__ int checkerboard_select(const float width, const float height, float x, float y) {
-    if (x >= 0) x = fmodf(x, width);
-    else        x = fmodf((fmodf((-x), width) + width / 2.0f), width);
-    if (y >= 0) y = fmodf(y, height);
-    else        y = fmodf((fmodf((-y), height) + height / 2.0f), height);
+#ifndef RT_NO_LEAN_FMOD
+    /* every lane that is here takes the short route, or none does */
+    if (!wave_any(!(fmod_small_quotient_ok(x, width) && fmod_small_quotient_ok(y, height)))) {
+        const float rw = __builtin_amdgcn_rcpf(width), rh = __builtin_amdgcn_rcpf(height);
+        if (x >= 0) x = fmod_small_quotient(x, width, rw);
+        else        x = fmod_small_quotient(fmod_small_quotient(-x, width, rw) + width / 2.0f, width, rw);
+        if (y >= 0) y = fmod_small_quotient(y, height, rh);
+        else        y = fmod_small_quotient(fmod_small_quotient(-y, height, rh) + height / 2.0f, height, rh);
+    } else
+#endif
+    {
+        if (x >= 0) x = fmodf(x, width);
+        else        x = fmodf((fmodf((-x), width) + width / 2.0f), width);
+        if (y >= 0) y = fmodf(y, height);
+        else        y = fmodf((fmodf((-y), height) + height / 2.0f), height);
+    }
     if (x < width / 2) return (y < height / 2) ? 1 : 2;
     return (y < height / 2) ? 2 : 1;
 }
@@ -705,7 +771,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 
     /* Bounce stack, [level][threadIdx.x], one 16-byte entry per reflective level
      * per lane.  It lives in LDS behind the scene tables when that keeps at
-     * least five workgroups per CU (small scenes, moderate depth); otherwise in
+     * least six workgroups per CU (small scenes, moderate depth); otherwise in
      * this workgroup's slice of an HBM buffer, written and read coalesced, so
      * that a large scene table alone decides the occupancy. */
     float4 *const lds_stack = lds + p.image_quads;
@@ -989,7 +1055,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     }
 }
 
-extern "C" __global__ void __launch_bounds__(256, 5)
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 6
+#endif
+extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
                  unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack) {
     render_body<false>(p, image, out, tile_counter, bounce_stack, nullptr);

@@ -86,6 +86,9 @@
 #define RT_MAX_GEOM_QUADS 65535   /* 16-bit geometry offset in objinfo */
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
 #define RT_MAX_LDS_BYTES  (160 * 1024)
+#ifndef RT_STACK_LDS_SHARE
+#define RT_STACK_LDS_SHARE 6      /* the bounce stack goes to LDS when tables + stack fit this many times per CU */
+#endif
 
 #define RT_TILE_STATS 6          /* counting build: words per wavefront tile {cycles, sphere tests, box tests, scans, start, end (100 MHz clock)} */
 
