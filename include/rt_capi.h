@@ -149,13 +149,15 @@ int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W,
  *     so these are comparable with each other, not with wall time)
  *   11, 12, 13 the same for the winner's collision record, the light loop
  *     (shadow scans included) and the reflection step
+ *   14, 15, 16 shadow scans: items left by the bundle cull, leaves some lane
+ *     needed, and (summed over scans) the most leaves one lane needed
  * wave_cycles (may be NULL) receives, per wavefront tile in row-major order
  * (tile = tile_row * tiles_x + tile_col), six words {shader cycles the
  * wavefront was resident, sphere tests it issued, box tests it issued, scans
  * it ran, start and end time on the 100 MHz constant clock}, up to
  * n_wave_cycles words.  out_rgb may be NULL.  The reference has no
  * counterpart (its gprof figures are quoted in SURVEY.md section 3.3). */
-#define RT_STATS_COUNT 14
+#define RT_STATS_COUNT 17
 int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                     int max_depth, float *out_rgb, uint64_t *stats, int n_stats,
                     uint64_t *wave_cycles, int n_wave_cycles);

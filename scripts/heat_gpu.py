@@ -30,3 +30,11 @@ for a, b in zip(edges[:-1], edges[1:]):
 late = np.argsort(end)[-8:]
 tx = t.shape[1]
 print("last finishers (tile_row, tile_col, start us, dur us):", [(int(i // tx), int(i % tx), int(start[i]), int(end[i]-start[i])) for i in late])
+heavy = np.argsort(t[..., 0].ravel())[-12:]
+print("heaviest tiles (tile_row, tile_col, Mcycles, sphere tests, box tests, start us, dur us):")
+for i in heavy:
+    r_, c_ = int(i // tx), int(i % tx)
+    print("  ", r_, c_, f"{t[r_, c_, 0] / 1e6:.2f}", int(t[r_, c_, 1]), int(t[r_, c_, 2]), int(start[i]), int(end[i] - start[i]))
+rows_ = t[..., 0].sum(axis=1)
+order = np.argsort(rows_)[-8:]
+print("heaviest tile rows (row, share of all cycles):", [(int(r_), round(float(rows_[r_] / rows_.sum()), 4)) for r_ in order])

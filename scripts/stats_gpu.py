@@ -14,6 +14,9 @@ for name, d in [("builtin", 4), ("grid32", 4), ("grid32-noshadow", 4), ("grid16"
         if k.startswith("cycles"):
             print(f"   {k:20s} {v:14d}   share of tile cycles: {v / max(st['cycles_tile'], 1):.3f}")
             continue
+        if k.startswith("shadow_") and k != "shadow_rays":
+            print(f"   {k:20s} {v:14d}   per shadow scan: {v / max(st['wave_shadow_scans'], 1):.2f}")
+            continue
         per = v / px if not k.startswith("wave") else v * 64 / px
         print(f"   {k:20s} {v:14d}   per pixel{' (x64 lanes)' if k.startswith('wave') else ''}: {per:10.2f}")
     ws, ls = st["wave_sphere_tests"] * 64, st["lane_sphere_tests"]

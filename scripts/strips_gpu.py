@@ -1,0 +1,25 @@
+"""Kernel time of each rank's x-strip on ONE GPU: what the static partition's load balance
+would be on N GPUs (development aid; the N-GPU runs themselves are the driver's)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tilecoderaytracer_amd import HostScene, Renderer
+from tilecoderaytracer_amd.distributed import strip_bounds
+import torch
+S = 4096
+for name, d in [("builtin", 4), ("grid32", 4)]:
+    r = Renderer(HostScene.named(name))
+    buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    def t(x0, x1, n=3):
+        r.render_device(S, S, d, x0, x1, buf.data_ptr(), st); torch.cuda.synchronize()
+        r.reset_timing()
+        for _ in range(n):
+            r.render_device(S, S, d, x0, x1, buf.data_ptr(), st)
+        torch.cuda.synchronize()
+        tm = r.timing()
+        return tm.sum_kernel_ms / tm.launches
+    full = t(0, S)
+    for N in (2, 4, 8):
+        ts = [t(*strip_bounds(S, N, k)[:2]) for k in range(N)]
+        print(f"{name:8s} N={N}: full {full:.3f} ms; strips " + " ".join(f"{x:.3f}" for x in ts) +
+              f"; max {max(ts):.3f} -> render-bound speedup {full / max(ts):.2f}x", flush=True)

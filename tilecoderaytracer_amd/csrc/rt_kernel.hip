@@ -94,6 +94,9 @@ enum {
     ST_CYCLES_WINNER,       /* ... on the winner's CollisionObject (point, normal, texture) */
     ST_CYCLES_LIGHTS,       /* ... in the light loop, shadow scans included                 */
     ST_CYCLES_REFLECT,      /* ... reflecting (phase 3)                                     */
+    ST_SHADOW_CANDIDATES,   /* wavefronts: items left by the shadow scans' bundle cull      */
+    ST_SHADOW_LEAVES_UNION, /* wavefronts: leaves some lane's segment needed                */
+    ST_SHADOW_LEAVES_MAXLANE, /* wavefronts: per scan, the most leaves one lane needed      */
     ST_COUNT
 };
 template <bool kStats> struct Stats { };
@@ -115,6 +118,13 @@ template <bool kStats> __device__ __forceinline__ void st_cycles(Stats<kStats> &
 template <> __device__ __forceinline__ void st_cycles<true>(Stats<true> &st, int k, unsigned long long since) {
     const unsigned int dt = (unsigned int)(__builtin_amdgcn_s_memtime() - since);
     st.c[k] += ((threadIdx.x & 63u) == 0u) ? dt : 0u;
+}
+
+template <bool kStats> __device__ __forceinline__ void st_maxlane(Stats<kStats> &, int, int) {}
+template <> __device__ __forceinline__ void st_maxlane<true>(Stats<true> &st, int k, int mine) {
+    int most = 0;
+    for (int l = 0; l < 64; ++l) most = max(most, __builtin_amdgcn_readlane(mine, l));
+    st.c[k] += ((threadIdx.x & 63u) == 0u) ? (unsigned int)most : 0u;
 }
 
 /* SceneSphere::collision reduced to its distance, src/SceneSphere.cpp:50-116.
@@ -242,6 +252,12 @@ __device__ __forceinline__ V3 aa_permute(const V3 v, const int cls) {
     }
 }
 
+/* relative growth of a box that must contain every sphere the reference's float
+ * arithmetic can report from a given origin; derived at box_needed() */
+#ifndef RT_SPHERE_SLACK
+#define RT_SPHERE_SLACK 1.5e-3f
+#endif
+
 __device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
     /* a NaN or infinity in any component makes the sum non-finite */
     return isfinite((fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)));
@@ -258,8 +274,11 @@ __device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
  *   the parameter of closest approach v_i >= -2.4e-7 D;
  * and its reported distance v - sqrt(d^2) is >= the parameter at which the ray
  * enters the ball B(c_i, r_eff), minus 2.4e-7 D.
- * Every such ball lies inside the box grown by `ex` = 4e-3 * far, where
- * far >= D is the L1 distance from the origin to the box's farthest corner.
+ * Every such ball lies inside the box grown by `ex` = RT_SPHERE_SLACK * far,
+ * where far >= D is the L1 distance from the origin to the box's farthest
+ * corner.  (The slack matters: shadow rays that start thousands of units away,
+ * on the ground plane near the horizon, pass high over a field of spheres, and
+ * a slack of 4e-3 made every leaf below them a candidate.)
  * So a slab test of the ray against the grown box decides: no intersection, or
  * exit behind the origin, or entry beyond `max_dist` (nearest distance so far /
  * distance to the light) => no member can matter.  The slab arithmetic itself
@@ -274,7 +293,7 @@ __device__ __forceinline__ bool box_needed(const float4 b0, const float4 b1, con
     const float y0 = b0.y - o.y, y1 = b1.y - o.y;
     const float z0 = b0.z - o.z, z1 = b1.z - o.z;
     const float far = fmaxf(fabsf(x0), fabsf(x1)) + fmaxf(fabsf(y0), fabsf(y1)) + fmaxf(fabsf(z0), fabsf(z1));
-    const float ex = 4.0e-3f * far;
+    const float ex = RT_SPHERE_SLACK * far;
     const float ax = (x0 - ex) * inv.x, bx = (x1 + ex) * inv.x;
     const float ay = (y0 - ex) * inv.y, by = (y1 + ex) * inv.y;
     const float az = (z0 - ex) * inv.z, bz = (z1 + ex) * inv.z;
@@ -338,6 +357,22 @@ __device__ __forceinline__ void wave_bounds3(const V3 v, const bool use, V3 *lo,
              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63)));
 }
 
+/* Wavefront-wide minimum of an unsigned key (all 64 lanes active), same DPP
+ * steps; a single chain, so the wait states are spelled out. */
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t k) {
+#define RT_DPP_STEP(ctrl) "s_nop 1\n v_min_u32_dpp %0, %0, %0 " ctrl "\n"
+    asm volatile(RT_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 RT_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n"
+                 : "+v"(k));
+#undef RT_DPP_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+}
+
 #ifdef RT_OLD_REDUCTIONS
 __device__ __forceinline__ float wave_min(float v) {
     v = fminf(v, dpp_f<RT_DPP_XOR1>(v));
@@ -381,6 +416,13 @@ __device__ __forceinline__ float wave_max(float v) {
  * Plain items are visited in Scene index order (strict `<` keeps the first of
  * equal distances, as the reference does); clustered groups come last and
  * break ties on the Scene index. */
+/* (t, idx) before (best, best_idx) in the order the reference's scan implies:
+ * nearer, or as near with a smaller Scene index (getCollision keeps the first
+ * of equals, src/RayTracer.cpp:71-80). */
+__device__ __forceinline__ bool nearer(const float t, const int idx, const float best, const int best_idx) {
+    return t < best || (t == best && idx < best_idx);
+}
+
 /* The bundle cull of nearest_hit_items() asks, per axis, for the t >= 0 with
  * t dmin <= b and t dmax >= a (dmin, dmax: the bundle's direction range; a, b:
  * the item box relative to the origin box).  Each inequality bounds t from
@@ -467,6 +509,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
 
     for (int base = 0; base < p.n_near_items; base += 64) {
         unsigned long long mask;
+        uint32_t key = 0xFFFFFFFFu;        /* this lane's item: bundle entry distance (high bits) | lane, see below */
         if (cull) {
             const int mine = min(base + lane, p.n_near_items - 1);
             const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
@@ -474,7 +517,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             float ay = b0.y - omaxy, by = b1.y - ominy;
             float az = b0.z - omaxz, bz = b1.z - ominz;
             const float far = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) + fmaxf(fabsf(az), fabsf(bz));
-            const float ex = 4.0e-3f * far + 1.0e-4f;
+            const float ex = RT_SPHERE_SLACK * far + 1.0e-4f;
             ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
             /* feasible t: [t_lo, t_hi], starting from [0, 65535 (the reference's infinity) + slack] */
 #ifndef RT_BRANCHY_CULL
@@ -496,14 +539,35 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             if (dmaxz > 0.0f) t_lo = fmaxf(t_lo, az * rxz); else if (dmaxz < 0.0f) t_hi = fminf(t_hi, az * rxz); else empty = empty || (az > 0.0f);
             empty = empty || (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi));
 #endif
-            mask = __builtin_amdgcn_ballot_w64(base + lane < p.n_near_items && !empty);
+            const bool candidate = base + lane < p.n_near_items && !empty;
+            mask = __builtin_amdgcn_ballot_w64(candidate);
+            if (candidate) key = (__float_as_uint(t_lo) & ~63u) | (uint32_t)lane;      /* t_lo >= 0: its bits order like its value */
         } else {
             const int left = p.n_near_items - base;
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
+        /* Many candidates: take them nearest first (by the bundle's entry distance into
+         * the item's box, a lower bound for every ray of it) and stop as soon as every
+         * lane already has a hit nearer than that -- rays grazing a field of spheres
+         * would otherwise test all of it.  The order of the tests does not change the
+         * result: the winner is the minimum of (distance, Scene index), which is what
+         * the reference's in-order scan with a strict `<` finds. */
+        const bool ordered = cull && __popcll(mask) >= RT_ORDER_MIN_CANDIDATES;
         while (mask != 0ull) {
-            const int item = base + (__ffsll((long long)mask) - 1);
-            mask &= mask - 1ull;
+            int src;
+            if (ordered) {
+                const uint32_t nearest_key = wave_min_u32(key);
+                if (nearest_key == 0xFFFFFFFFu) break;                 /* cannot happen while mask != 0; keeps the loop finite regardless */
+                src = (int)(nearest_key & 63u);
+                const float entry = __uint_as_float(nearest_key & ~63u);
+                if (!wave_any(active && !(entry - 1.0e-4f * entry - 1.0e-6f > best))) break;
+                if (lane == src) key = 0xFFFFFFFFu;
+                mask &= ~(1ull << src);
+            } else {
+                src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1ull;
+            }
+            const int item = base + src;
             const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
             const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
             const int kind = (int)(bits & 15u);
@@ -513,7 +577,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             if (kind == RT_KIND_SPHERE) {
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, active);
                 sphere_distance(g[0], o, d, &hit, &t);
-                if (hit && t < best) { best = t; best_idx = idx; }
+                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
             } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run; bits1 = its members' Scene indices */
                 const int n = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
@@ -526,7 +590,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                     sphere_distance(g[i], o, d, &hit, &t);
                     if (wave_any(hit)) {
                         const int member = (int)ids[i];
-                        if (hit && (t < best || (t == best && member < best_idx))) { best = t; best_idx = member; }
+                        if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
                     }
                 }
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves; bits1 = its Scene-index table */
@@ -547,23 +611,23 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                         sphere_distance(m[i], o, d, &hit, &t);
                         if (wave_any(hit)) {
                             const int member = (int)ids[i];
-                            if (hit && (t < best || (t == best && member < best_idx))) { best = t; best_idx = member; }
+                            if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
                         }
                     }
                 }
             } else if (kind == RT_KIND_INFINITE_PLANE) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 infinite_plane_distance(g[0], o, d, best, &hit, &t);
-                if (hit && t < best) { best = t; best_idx = idx; }
+                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
             } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 6 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 const int cls = kind - RT_KIND_FINITE_AA;
                 aa_rectangle_distance(g[0], g[1], aa_permute(o, cls), aa_permute(d, cls), best, &hit, &t);
-                if (hit && t < best) { best = t; best_idx = idx; }
+                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 finite_plane_distance(lds + (bits1 >> 12), o, d, best, &hit, &t);
-                if (hit && t < best) { best = t; best_idx = idx; }
+                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
             }
         }
     }
@@ -583,7 +647,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
  * candidates get the exact per-lane tests.  An object can only block if the
  * reference finds a hit with 0 < distance < dist_to_light; that hit point is
  * within rounding of the segment and of the object, so both boxes contain it
- * once grown by `fuzz` (the item boxes are inflated on the host, B here: 4e-3 of
+ * once grown by `fuzz` (the item boxes are inflated on the host, B here: RT_SPHERE_SLACK of
  * its size covers the sphere routine's distance-dependent slack, see
  * box_needed()).  A NaN bound compares "overlapping".  Blocking is a boolean OR,
  * so order does not matter. */
@@ -592,6 +656,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
                                          const V3 origins_lo, const V3 origins_hi, Stats<kStats> &st) {
     bool blocked = !active;
+    int stat_my_leaves = 0;
     if (p.n_shadow_items == 0) return false;
     st_lane(st, ST_SHADOW_RAYS, active);
     st_wave(st, ST_WAVE_SHADOW);
@@ -611,7 +676,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                fmaxf(origins_hi.z - c.z, c.z - origins_lo.z) * 1.000001f);
         const V3 seg = sub3(light, c);
         sinv = approx_inverse(seg);
-        grow = 4.0e-3f * ((fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z)) + 1.0e-4f;
+        grow = RT_SPHERE_SLACK * ((fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z)) + 1.0e-4f;
         /* all of these are the same in every lane: keep them in scalar registers */
         c = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
         e = mk(uniform_f(e.x + grow), uniform_f(e.y + grow), uniform_f(e.z + grow));
@@ -641,10 +706,12 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
             const int left = p.n_shadow_items - base;
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
+        uint32_t my_leaves_lo = 0u, my_leaves_hi = 0u;     /* leaves of this chunk whose box this lane's segment meets */
+        if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
         while (mask != 0ull) {
             const int item = base + (__ffsll((long long)mask) - 1);
             mask &= mask - 1ull;
-            if (!wave_any(!blocked)) return true;
+            if (!wave_any(!blocked)) { st_maxlane(st, ST_SHADOW_LEAVES_MAXLANE, stat_my_leaves); return true; }
             const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
             const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
             const int kind = (int)(bits & 15u);
@@ -658,7 +725,16 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 const int n = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
+#ifdef RT_PER_LANE_LEAVES
+                /* only note which lanes need this leaf; the leaves are walked lane by lane below */
+                const int src = item - base;
+                if (src < 32) my_leaves_lo |= lane_needs ? (1u << src) : 0u;
+                else          my_leaves_hi |= lane_needs ? (1u << (src - 32)) : 0u;
+                continue;
+#endif
                 if (!wave_any(lane_needs)) continue;
+                st_wave(st, ST_SHADOW_LEAVES_UNION);
+                if constexpr (kStats) stat_my_leaves += lane_needs ? 1 : 0;
 #pragma unroll 2
                 for (int i = 0; i < n; ++i) {
                     st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
@@ -698,7 +774,31 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 blocked = blocked || (hit && t < dist_to_light);
             }
         }
+#ifdef RT_PER_LANE_LEAVES
+        /* Every lane walks ITS leaves (lowest item first), all lanes in step: the
+         * loop runs as long as the lane with the most leaves left, not once per
+         * leaf that any lane needs.  Neighbouring segments that graze a field of
+         * spheres need different leaves; walking the union would cost each lane
+         * the whole wavefront's list.  Any blocker ends a lane's walk. */
+        for (;;) {
+            const bool walking = !blocked && (my_leaves_lo | my_leaves_hi) != 0u;
+            if (!wave_any(walking)) break;
+            const int bit = my_leaves_lo != 0u ? __ffs((int)my_leaves_lo) - 1 : 31 + __ffs((int)my_leaves_hi);
+            if (my_leaves_lo != 0u) my_leaves_lo &= my_leaves_lo - 1u;
+            else                    my_leaves_hi &= my_leaves_hi - 1u;
+            const uint32_t w = walking ? __float_as_uint(items[2 * (base + (bit & 63))].w) : 0u;
+            const int n = (int)((w >> 8) & 255u);
+            const float4 *members = lds + (w >> 16);
+            for (int i = 0; wave_any(i < n); ++i) {
+                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i < n);
+                bool hit; float t;
+                sphere_distance(members[i < n ? i : 0], o, d, &hit, &t);
+                blocked = blocked || (i < n && hit && t < dist_to_light);
+            }
+        }
+#endif
     }
+    st_maxlane(st, ST_SHADOW_LEAVES_MAXLANE, stat_my_leaves);
     return blocked;
 }
 

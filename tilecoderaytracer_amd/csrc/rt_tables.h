@@ -102,6 +102,10 @@
 #define RT_NEAR_CULL_MIN_ITEMS 8     /* below this many items the nearest scan skips the bundle cull */
 #define RT_SHADOW_CULL_MIN_ITEMS 8   /* below this many shadow items the wavefront skips the bundle-box cull */
 
+#ifndef RT_ORDER_MIN_CANDIDATES
+#define RT_ORDER_MIN_CANDIDATES 4    /* from this many candidates on the nearest scan takes them nearest first */
+#endif
+
 #define RT_STACK_ENTRY_BYTES 16   /* {local.rgb, bits(object index | texsel << 16)} per bounce level per lane */
 
 typedef struct RtParams {
