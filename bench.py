@@ -25,6 +25,10 @@ Extra objects on the JSON line:
                 (12 B per pixel: one packed fp32 RGB store) / average kernel
                 duration, measured with HIP events on the launch stream inside
                 the timed region.
+  sphere_grid   (default workload only) the same partition timed on the
+                1024-sphere grid scene, BASELINE.json configs[2], the scene the
+                north star quotes for the 1/2/4/8-GPU series; a few steps, after
+                and outside the headline timed region.
   cpu_baseline  the CPU oracle (oracle/rt_oracle.c, a port of the reference's
                 algorithm; the reference itself is unbuildable here) timed on
                 this host's cores on a bounded sample of the same workload.
@@ -60,6 +64,8 @@ def parse_args():
     ap.add_argument("--workload", default="builtin", choices=sorted(WORKLOADS))
     ap.add_argument("--size", type=int, default=0, help="override W=H (a non-standard run; recorded in config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the short sphere-grid measurement that follows the default workload")
     ap.add_argument("--cpu-sample-columns", type=int, default=0,
                     help="columns of the image the CPU oracle renders (default: sized for ~10-30 CPU-seconds)")
     ap.add_argument("--tile-z", type=int, default=0, help="wavefront tile height override (speed only)")
@@ -173,47 +179,71 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    scene_name, W, H, depth, cfg_note = WORKLOADS[args.workload]
-    if args.size:
-        W = H = args.size
-    host = HostScene.named(scene_name)
-    renderer = Renderer(host, device=local_rank)
-    if args.tile_z:
-        renderer.set_option("tile_z", args.tile_z)
-    if args.block_threads:
-        renderer.set_option("block_threads", args.block_threads)
-    for kv in args.option:
-        k, v = kv.split("=")
-        renderer.set_option(k, int(v))
-
     stream = torch.cuda.current_stream(dev).cuda_stream
-    pipe = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap, force_gather=args.force_dist)
-    x0, x1, strip = pipe.x0, pipe.x1, pipe.strip
-    pipe.render = lambda buf: renderer.render_device(W, H, depth, x0, x1, buf.data_ptr(), stream)
-    step = pipe.step
 
-    def fence():
-        pipe.drain()
+    def measure(workload, steps, warmup, size=0):
+        """Warm up, then time exactly `steps` steps of `workload` between two fences
+        (barrier + synchronize); returns the MAX over ranks."""
+        scene_name, W, H, depth, cfg_note = WORKLOADS[workload]
+        if size:
+            W = H = size
+        host = HostScene.named(scene_name)
+        renderer = Renderer(host, device=local_rank)
+        if args.tile_z:
+            renderer.set_option("tile_z", args.tile_z)
+        if args.block_threads:
+            renderer.set_option("block_threads", args.block_threads)
+        for kv in args.option:
+            k, v = kv.split("=")
+            renderer.set_option(k, int(v))
+        pipe = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap, force_gather=args.force_dist)
+        x0, x1 = pipe.x0, pipe.x1
+        pipe.render = lambda buf: renderer.render_device(W, H, depth, x0, x1, buf.data_ptr(), stream)
+
+        def fence():
+            pipe.drain()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(warmup):
+            pipe.step()
+        fence()
+        renderer.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        tm = renderer.timing()
+        kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, kernel_ms = float(t[0]), float(t[1])
+        return dict(scene_name=scene_name, W=W, H=H, depth=depth, cfg_note=cfg_note, host=host, renderer=renderer,
+                    x0=x0, x1=x1, strip=pipe.strip, elapsed=elapsed, kernel_ms=kernel_ms)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    renderer.reset_timing()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    tm = renderer.timing()
-    kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
+    m = measure(args.workload, args.steps, args.warmup, args.size)
+    scene_name, W, H, depth, cfg_note = m["scene_name"], m["W"], m["H"], m["depth"], m["cfg_note"]
+    host, renderer, x0, x1, strip = m["host"], m["renderer"], m["x0"], m["x1"], m["strip"]
+    elapsed, kernel_ms = m["elapsed"], m["kernel_ms"]
 
-    if use_dist:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    # the north star also asks for the sphere-grid scene at every GPU count: a short second
+    # measurement of configs[2] with the same partition, reported next to the headline value
+    grid = None
+    if args.workload == "builtin" and not args.size and not args.no_extra:
+        g_steps = max(3, args.steps // 5)
+        g = measure("grid32", g_steps, 2)
+        grid = {
+            "workload": f"{g['scene_name']} scene, {g['W']}x{g['H']}, max depth {g['depth']}",
+            "baseline_config": g["cfg_note"],
+            "value": round(g["W"] * g["H"] * g_steps / g["elapsed"] / 1e6, 3),
+            "unit": "Mrays/s",
+            "steps": g_steps,
+            "ms_per_step": round(g["elapsed"] / g_steps * 1e3, 4),
+            "kernel_ms": round(g["kernel_ms"], 4),
+        }
 
     if rank == 0:
         li = renderer.launch_info()
@@ -267,6 +297,8 @@ def main():
                         "the kernel is fp32-VALU-bound (non-FMA), see DESIGN.md",
             },
         }
+        if grid is not None:
+            out["sphere_grid"] = grid
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cols = args.cpu_sample_columns or {"builtin": 4096, "builtin8k": 2048}.get(args.workload, 64)

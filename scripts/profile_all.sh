@@ -9,9 +9,9 @@ R=$PWD
 O=$R/gpurun_out/$D
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 1"
+B="python3 $R/bench.py --no-cpu-baseline --no-extra --steps 5 --warmup 1"
 if [ $WHAT = all ]; then
-  rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5 > $O/trace.log 2>&1
   for w in grid32 grid16d8; do
     rocprofv3 --kernel-trace --stats -d $O/trace_$w --output-format csv -- $B --workload $w > $O/trace_$w.log 2>&1
   done

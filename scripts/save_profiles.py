@@ -7,7 +7,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "profiles")
 
 def one(pattern):
-    g = sorted(glob.glob(os.path.join(src, pattern)))
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)     # newest run of that pass
     return g[-1] if g else None
 
 def rows(path, want="rt_render_kernel"):
@@ -48,6 +48,15 @@ with open(os.path.join(P, f"{tag}_builtin4096d4_pmc_sq.csv"), "w") as f:
     wr = csv.writer(f)
     first = True
     for d in ("sq1", "sq2"):
+        path = one(f"{d}/*/*_counter_collection.csv")
+        if not path: continue
+        h, rs = rows(path)
+        if first: wr.writerow(h); first = False
+        wr.writerows(rs[-8:])
+with open(os.path.join(P, f"{tag}_grid32_pmc_sq.csv"), "w") as f:
+    wr = csv.writer(f)
+    first = True
+    for d in ("sq1_grid32", "sq2_grid32"):
         path = one(f"{d}/*/*_counter_collection.csv")
         if not path: continue
         h, rs = rows(path)

@@ -305,6 +305,15 @@ __device__ __forceinline__ bool box_needed(const float4 b0, const float4 b1, con
     return !(miss || behind || beyond);
 }
 
+/* A wave-uniform value, made opaque at the point of use: whatever is derived
+ * from it (a per-lane address, an int -> float conversion) is then computed
+ * there, instead of being hoisted out of the tile loop into a vector register
+ * that lives -- or is spilled -- across the scans. */
+__device__ __forceinline__ int here(int scalar_register_value) {      /* a kernel argument, a workgroup id: already in an SGPR */
+    asm volatile("" : "+s"(scalar_register_value));
+    return scalar_register_value;
+}
+
 __device__ __forceinline__ float uniform_f(const float v) {
 #ifdef RT_NO_UNIFORM
     return v;
@@ -706,7 +715,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
             const int left = p.n_shadow_items - base;
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
-        uint32_t my_leaves_lo = 0u, my_leaves_hi = 0u;     /* leaves of this chunk whose box this lane's segment meets */
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
         while (mask != 0ull) {
             const int item = base + (__ffsll((long long)mask) - 1);
@@ -725,13 +733,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 const int n = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
-#ifdef RT_PER_LANE_LEAVES
-                /* only note which lanes need this leaf; the leaves are walked lane by lane below */
-                const int src = item - base;
-                if (src < 32) my_leaves_lo |= lane_needs ? (1u << src) : 0u;
-                else          my_leaves_hi |= lane_needs ? (1u << (src - 32)) : 0u;
-                continue;
-#endif
                 if (!wave_any(lane_needs)) continue;
                 st_wave(st, ST_SHADOW_LEAVES_UNION);
                 if constexpr (kStats) stat_my_leaves += lane_needs ? 1 : 0;
@@ -774,29 +775,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 blocked = blocked || (hit && t < dist_to_light);
             }
         }
-#ifdef RT_PER_LANE_LEAVES
-        /* Every lane walks ITS leaves (lowest item first), all lanes in step: the
-         * loop runs as long as the lane with the most leaves left, not once per
-         * leaf that any lane needs.  Neighbouring segments that graze a field of
-         * spheres need different leaves; walking the union would cost each lane
-         * the whole wavefront's list.  Any blocker ends a lane's walk. */
-        for (;;) {
-            const bool walking = !blocked && (my_leaves_lo | my_leaves_hi) != 0u;
-            if (!wave_any(walking)) break;
-            const int bit = my_leaves_lo != 0u ? __ffs((int)my_leaves_lo) - 1 : 31 + __ffs((int)my_leaves_hi);
-            if (my_leaves_lo != 0u) my_leaves_lo &= my_leaves_lo - 1u;
-            else                    my_leaves_hi &= my_leaves_hi - 1u;
-            const uint32_t w = walking ? __float_as_uint(items[2 * (base + (bit & 63))].w) : 0u;
-            const int n = (int)((w >> 8) & 255u);
-            const float4 *members = lds + (w >> 16);
-            for (int i = 0; wave_any(i < n); ++i) {
-                st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i < n);
-                bool hit; float t;
-                sphere_distance(members[i < n ? i : 0], o, d, &hit, &t);
-                blocked = blocked || (i < n && hit && t < dist_to_light);
-            }
-        }
-#endif
     }
     st_maxlane(st, ST_SHADOW_LEAVES_MAXLANE, stat_my_leaves);
     return blocked;
@@ -853,6 +831,14 @@ __device__ __forceinline__ V3 entry_colour(const RtParams &p, const float4 *lds,
 
 } // namespace
 
+/* Entry [level][threadIdx.x] of this workgroup's slice of the HBM bounce stack.
+ * Computed where it is used, from scalar pieces (the host keeps the whole
+ * buffer below 2^32 entries), so no per-lane address lives across the scans. */
+__device__ __forceinline__ size_t hbm_stack_entry(const RtParams &p, const int level) {
+    const unsigned int row = (unsigned int)here((int)blockIdx.x) * (unsigned int)(p.max_depth + 1) + (unsigned int)level;
+    return (size_t)(row * blockDim.x + threadIdx.x);
+}
+
 template <bool kStats>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
@@ -874,8 +860,6 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * least six workgroups per CU (small scenes, moderate depth); otherwise in
      * this workgroup's slice of an HBM buffer, written and read coalesced, so
      * that a large scene table alone decides the occupancy. */
-    float4 *const lds_stack = lds + p.image_quads;
-    float4 *const hbm_stack = bounce_stack + (size_t)blockIdx.x * (size_t)(p.max_depth + 1) * blockDim.x;
     const bool stack_in_lds = p.stack_in_lds != 0;
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
 
@@ -899,7 +883,6 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * active here and every wavefront walks all 8 queues to their end, so the
      * grid always drains. */
     const int lane = threadIdx.x & 63;
-    const int tz = 1 << p.tile_z_log2;
     const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
     const int macro_rows = (p.tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
     const int n_macros = macro_rows * p.tiles_x;
@@ -930,8 +913,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 
     /* pixel of this lane: wavefront tiles are tile_x columns by tile_z rows;
      * consecutive lanes walk z, the contiguous axis of pixels[x][z] */
-    const int x = p.x0 + tile_col * (64 >> p.tile_z_log2) + (lane >> p.tile_z_log2);
-    const int z = tile_row * tz + (lane & (tz - 1));
+    const int tzl_a = here(p.tile_z_log2);
+    const int x = p.x0 + tile_col * (64 >> tzl_a) + (lane >> tzl_a);
+    const int z = (tile_row << tzl_a) + (lane & ((1 << tzl_a) - 1));
     const bool inside = (x < p.x1) && (z < p.H);
 
     /* Camera::createEyeRay, src/Camera.cpp:71-84, with dx = (float)x / W,
@@ -939,8 +923,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     V3 o = mk(p.eye[0], p.eye[1], p.eye[2]);
     V3 d;
     {
-        const float dx_percent = ((float)x) / (float)p.W;
-        const float dy_percent = ((float)z) / (float)p.H;
+        const float dx_percent = ((float)x) / (float)here(p.W);
+        const float dy_percent = ((float)z) / (float)here(p.H);
         const float scalar_x = dx_percent * p.sw - p.shw;
         const float scalar_y = dy_percent * p.sh - p.shh;
         V3 pixel = add3(mk(p.so[0], p.so[1], p.so[2]), scale3(mk(p.ch[0], p.ch[1], p.ch[2]), scalar_x));
@@ -1025,8 +1009,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             /* box of the shading points, shared by every light's shadow scan */
             have_box = p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
             if (have_box) {
-                const float inf = __builtin_huge_valf();
 #ifdef RT_OLD_REDUCTIONS
+                const float inf = __builtin_huge_valf();
                 box_lo = mk(wave_min(shade ? P.x : inf), wave_min(shade ? P.y : inf), wave_min(shade ? P.z : inf));
                 box_hi = mk(wave_max(shade ? P.x : -inf), wave_max(shade ? P.y : -inf), wave_max(shade ? P.z : -inf));
 #else
@@ -1095,8 +1079,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 float4 e;
                 e.x = C.x; e.y = C.y; e.z = C.z;
                 e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
-                if (stack_in_lds) lds_stack[level * blockDim.x + threadIdx.x] = e;
-                else              hbm_stack[level * blockDim.x + threadIdx.x] = e;
+                if (stack_in_lds) lds[here(p.image_quads) + level * blockDim.x + threadIdx.x] = e;
+                else              bounce_stack[hbm_stack_entry(p, level)] = e;
                 top = level + 1;
                 o = P;
                 d = normalize3(reflected);                   /* Ray(point, reflected) */
@@ -1112,7 +1096,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     /* unwind: final_k = local_k + (rf_k * C_{k+1}) * oc_k, inside-out (:601) */
     for (int k = levels - 1; k >= 0; --k) {
         if (k < top) {
-            const float4 e = stack_in_lds ? lds_stack[k * blockDim.x + threadIdx.x] : hbm_stack[k * blockDim.x + threadIdx.x];
+            const float4 e = stack_in_lds ? lds[here(p.image_quads) + k * blockDim.x + threadIdx.x] : bounce_stack[hbm_stack_entry(p, k)];
             const uint32_t bits = __float_as_uint(e.w);
             const uint32_t info = lds_u32[p.objinfo_off * 4 + (bits & 0xFFFFu)];
             const int mat = (int)(info >> 20);
@@ -1125,8 +1109,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     }
 
     if (inside) {
-        const int sx = tile_col * (64 >> p.tile_z_log2) + (lane >> p.tile_z_log2);   /* x - x0 */
-        const int sz = tile_row * tz + (lane & (tz - 1));
+        const int tzl_b = here(p.tile_z_log2);
+        const int sx = tile_col * (64 >> tzl_b) + (lane >> tzl_b);   /* x - x0 */
+        const int sz = (tile_row << tzl_b) + (lane & ((1 << tzl_b) - 1));
         float *dst = out + ((size_t)sx * (size_t)p.H + (size_t)sz) * 3;
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
     }
