@@ -165,8 +165,12 @@ int aa_class(const rt_object_desc &o, float *sn, float *sh, float *sv, int *a_ax
                            o.distance_to_origin};
     for (float f : vals) if (!std::isfinite(f)) return -1;
     if (o.h_distance < 0.0f || o.v_distance < 0.0f) return -1;
+    /* The record lists the two in-plane axes in cyclic order after the normal's
+     * ((kn+1)%3, then (kn+2)%3), whichever of them is "horizontal": the bounds test
+     * treats both alike, so the kernel needs the normal's axis only. */
+    if (kh != (kn + 1) % 3) { std::swap(*sh, *sv); *a_axis = kv; *b_axis = kh; return kn + 3; }
     *a_axis = kh; *b_axis = kv;
-    return 2 * kn + (kh == (kn + 1) % 3 ? 0 : 1);
+    return kn;
 }
 
 bool all_finite(const rt_object_desc &o) {
@@ -336,9 +340,11 @@ int pack_scene(rt_scene *s) {
         const int cls = aa_class(objs[i], &sn, &sh, &sv, &ka, &kb);
         const rt_object_desc &o = objs[i];
         aa_rec_of[(size_t)i] = (int)aa_recs.size();
-        aa_cls_of[(size_t)i] = cls;
+        aa_cls_of[(size_t)i] = cls % 3;
+        const bool swapped = cls >= 3;                   /* first in-plane axis is the plane's "vertical" */
         aa_recs.push_back({{o.distance_to_origin, sn, sh, sv}});
-        aa_recs.push_back({{o.plane_origin[ka], o.plane_origin[kb], o.h_distance, o.v_distance}});
+        aa_recs.push_back({{o.plane_origin[ka], o.plane_origin[kb], swapped ? o.v_distance : o.h_distance,
+                            swapped ? o.h_distance : o.v_distance}});
     }
     for (int i = 0; i < n; ++i)
         objinfo[(size_t)i] = (uint32_t)geom_off[(size_t)i] | ((uint32_t)objs[i].kind << 16) |

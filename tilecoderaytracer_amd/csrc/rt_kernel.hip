@@ -239,24 +239,19 @@ __device__ __forceinline__ void aa_rectangle_distance(const float4 r0, const flo
     }
 }
 
-/* components of v in the order (normal axis, horizontal axis, vertical axis) of an AA class:
- * class = 2*n_axis + (h_axis == (n_axis+1)%3 ? 0 : 1) */
-__device__ __forceinline__ V3 aa_permute(const V3 v, const int cls) {
-    switch (cls) {
-    case 0: return mk(v.x, v.y, v.z);
-    case 1: return mk(v.x, v.z, v.y);
-    case 2: return mk(v.y, v.z, v.x);
-    case 3: return mk(v.y, v.x, v.z);
-    case 4: return mk(v.z, v.x, v.y);
-    default: return mk(v.z, v.y, v.x);
-    }
-}
 
 /* relative growth of a box that must contain every sphere the reference's float
  * arithmetic can report from a given origin; derived at box_needed() */
 #ifndef RT_SPHERE_SLACK
 #define RT_SPHERE_SLACK 1.5e-3f
 #endif
+
+/* (v[axis], v[axis+1], v[axis+2]), indices mod 3, for a wave-uniform axis */
+__device__ __forceinline__ V3 rotate_axes(const V3 v, const int axis) {
+    if (axis == 0) return v;
+    if (axis == 1) return mk(v.y, v.z, v.x);
+    return mk(v.z, v.x, v.y);
+}
 
 __device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
     /* a NaN or infinity in any component makes the sum non-finite */
@@ -628,10 +623,10 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 infinite_plane_distance(g[0], o, d, best, &hit, &t);
                 if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
-            } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 6 && finite_rays) {
+            } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 3 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                const int cls = kind - RT_KIND_FINITE_AA;
-                aa_rectangle_distance(g[0], g[1], aa_permute(o, cls), aa_permute(d, cls), best, &hit, &t);
+                const int axis = kind - RT_KIND_FINITE_AA;             /* of the normal; the record is in cyclic order from it */
+                aa_rectangle_distance(g[0], g[1], rotate_axes(o, axis), rotate_axes(d, axis), best, &hit, &t);
                 if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
@@ -764,10 +759,10 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 infinite_plane_distance(g[0], o, d, dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
-            } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 6 && finite_rays) {
+            } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 3 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                const int cls = kind - RT_KIND_FINITE_AA;
-                aa_rectangle_distance(g[0], g[1], aa_permute(o, cls), aa_permute(d, cls), dist_to_light, &hit, &t);
+                const int axis = kind - RT_KIND_FINITE_AA;
+                aa_rectangle_distance(g[0], g[1], rotate_axes(o, axis), rotate_axes(d, axis), dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);

@@ -49,7 +49,7 @@
  *   {box lo.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
  *   {box hi.xyz, bits(Scene index | quad offset of the full 5-quad plane record << 12)}
  * kind = RT_KIND_SPHERE / _INFINITE_PLANE / _FINITE_PLANE;
- *        RT_KIND_FINITE_AA + class for an axis-aligned rectangle (geometry
+ *        RT_KIND_FINITE_AA + normal axis for an axis-aligned rectangle (geometry
  *        offset = its aa record);
  *        RT_KIND_SPHERE_CLUSTERED for a group (count = its leaves, geometry
  *        offset = its first leaf record, second word = u32 index of the run's
@@ -73,8 +73,9 @@
 /* item kinds: RT_KIND_* of rt_capi.h (0 sphere, 1 infinite plane, 2 finite
  * plane), plus a group of leaves of a clustered sphere run ... */
 #define RT_KIND_SPHERE_CLUSTERED 3
-/* ... and axis-aligned finite planes, six classes by axis permutation:
- * kind = 4 + class, class = 2*normal_axis + (horizontal_axis == (normal_axis+1)%3 ? 0 : 1).
+/* ... and axis-aligned finite planes: kind = 4 + axis of the normal (0 x, 1 y, 2 z).
+ * Their 2-quad test record lists the two in-plane axes in cyclic order after the
+ * normal's: {dto, sign_n, sign_a, sign_b}, {origin_a, origin_b, extent_a, extent_b}.
  * The full 5-quad record of each plane is kept too (winner record, non-finite rays). */
 #define RT_KIND_FINITE_AA 4
 /* one leaf of a clustered sphere run as an item: count = its members, geometry
