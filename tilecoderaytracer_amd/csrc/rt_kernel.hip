@@ -1135,8 +1135,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     }
 }
 
+/* 72 VGPRs: seven wavefronts per SIMD where LDS allows (the bounce stack keeps
+ * its LDS place up to six workgroups per CU, RT_STACK_LDS_SHARE) */
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 6
+#define RT_WAVES_PER_SIMD 7
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
