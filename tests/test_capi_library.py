@@ -112,3 +112,35 @@ def test_product_does_not_reference_the_oracle():
     for lib in ("libtcrt.so", "libtcrt_host.so"):
         blob = open(os.path.join(pkg, "lib", lib), "rb").read()
         assert b"orc_render" not in blob and b"liboracle" not in blob
+
+
+def test_build_keeps_the_arithmetic_contract_flags():
+    """Parity depends on how the kernel is compiled: no FMA
+    contraction, correctly rounded fp32 divide/sqrt, denormals kept, never fast-math."""
+    mk = open(os.path.join(ROOT, "tilecoderaytracer_amd", "csrc", "Makefile")).read()
+    flags = re.search(r"^HIPFLAGS\s*:=(.*?)(?:\n\S|\Z)", mk, flags=re.S | re.M).group(1)
+    for needed in ("--offload-arch=$(ARCH)", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                   "-fno-gpu-flush-denormals-to-zero", "-fno-fast-math"):
+        assert needed in flags, needed
+    assert "-ffast-math" not in flags.replace("-fno-fast-math", "")
+    assert re.search(r"^ARCH\s*\?=\s*gfx950", mk, flags=re.M)
+    kernel = open(os.path.join(ROOT, "tilecoderaytracer_amd", "csrc", "rt_kernel.hip")).read()
+    assert "#pragma clang fp contract(off)" in kernel
+
+
+def test_library_path_can_be_overridden(monkeypatch, tmp_path):
+    """TCRT_LIBRARY names another build of libtcrt.so (A/B timing, packaging)."""
+    default = capi.library_path()
+    assert default.endswith(os.path.join("lib", "libtcrt.so"))
+    other = tmp_path / "libtcrt_other.so"
+    monkeypatch.setenv("TCRT_LIBRARY", str(other))
+    assert capi.library_path() == str(other)
+    monkeypatch.delenv("TCRT_LIBRARY")
+    assert capi.library_path() == default
+
+
+def test_counting_build_names_match_the_header():
+    from tilecoderaytracer_amd import Renderer
+    text = open(os.path.join(ROOT, "include", "rt_capi.h")).read()
+    count = int(re.search(r"#define RT_STATS_COUNT (\d+)", text).group(1))
+    assert len(Renderer.STAT_NAMES) == count
