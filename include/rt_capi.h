@@ -166,8 +166,15 @@ int rt_get_timing(const rt_scene *scene, rt_timing *out);
 int rt_reset_timing(rt_scene *scene);
 int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
 
-/* Tuning knobs (speed only, never results).  key: "tile_z" (wavefront tile
- * height: 1,2,4,...,64), "block_threads" (0 = auto, else 64..1024). */
+/* Tuning knobs (speed only, never results).  key:
+ *   "tile_z"        wavefront tile height, 1,2,4,...,64 (width = 64 / height)
+ *   "block_threads" 0 = auto, else 64..1024
+ *   "stack"         bounce stack: 0 auto, 1 LDS, 2 HBM
+ *   "grid_mult"     persistent grid = occupancy x CUs x this; 0 = no persistence
+ *   "first_row"     where the tile queues start, thousandths of the image
+ *                   height (rows wrap around); -1 = automatic
+ *   "aa_planes"     0 switches the axis-aligned rectangle route off
+ *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */
 int rt_set_option(rt_scene *scene, const char *key, int value);
 
 int         rt_device_count(int *count);

@@ -8,6 +8,9 @@ import torch
 S = 4096
 for name, d in [("builtin", 4), ("grid32", 4)]:
     r = Renderer(HostScene.named(name))
+    for a in sys.argv[1:]:
+        if "=" in a:
+            r.set_option(a.split("=")[0], int(a.split("=")[1]))
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     def t(x0, x1, n=3):

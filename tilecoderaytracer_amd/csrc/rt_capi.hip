@@ -75,6 +75,7 @@ struct rt_scene {
     int tile_z_log2 = -1;         /* wavefront tile height: -1 = auto (see launch()), else log2 */
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
+    int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int leaf_items_opt = 1;       /* clustered runs appear in the item tables leaf by leaf (0: group by group) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
@@ -566,6 +567,39 @@ int drain_event(rt_scene *s, int i) {
     return RT_OK;
 }
 
+/* Where the tile queues start (thousandths of the image height; the rows wrap
+ * around).  Scheduling only.  The most expensive tiles of a frame should not be
+ * the last ones handed out, and with clustered sphere runs in the scene there is
+ * one place where they are known to be: where primary rays graze an infinite
+ * plane.  Hit points thousands of units away make every leaf of every run a
+ * candidate of their shadow rays (the reference's float sphere test is that
+ * coarse out there, box_needed() in rt_kernel.hip), so those few pixel rows cost
+ * 10-100 x the median tile -- a single wavefront works milliseconds on one.
+ * Starting just below the horizon row (image centre column) puts them first:
+ * 15 % on the 1 024-sphere grid frame, more on the strips of a multi-GPU frame.
+ * Without clustered runs the natural order (bottom row first) is kept. */
+int horizon_start(const rt_scene *s, const rt_camera_desc *cam) {
+    if (s->n_clusters <= 0) return 0;
+    double best = -1.0;
+    for (const rt_object_desc &o : s->objects) {
+        if (o.kind != RT_KIND_INFINITE_PLANE) continue;
+        /* direction of the centre column's pixel at height dz in [0,1] (src/Camera.cpp:71-84), dotted with n: A + B dz */
+        double a = 0.0, b = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            const double centre = (double)cam->screen_origin[c] +
+                                  (double)cam->vector_horizontal[c] * (0.5 * cam->screen_width - cam->screen_halfwidth) -
+                                  (double)cam->vector_vertical[c] * cam->screen_halfheight - (double)cam->eye_origin[c];
+            a += centre * o.normal[c];
+            b += (double)cam->vector_vertical[c] * cam->screen_height * o.normal[c];
+        }
+        if (!(std::fabs(b) > 0.0)) continue;
+        const double dz = -a / b;
+        if (dz > 0.0 && dz < 1.0 && (best < 0.0 || dz < best)) best = dz;
+    }
+    if (best < 0.0) return 0;
+    return std::max(0, (int)(best * 1000.0) - 8);
+}
+
 /* Workgroup size and where the bounce stack goes.  The stack (16 B per level
  * per thread) shares LDS with the scene tables when the sum stays within
  * 160 KiB / 6, i.e. six workgroups per CU still fit; otherwise it moves to
@@ -622,6 +656,12 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if (n_tiles > 0x7fffffffLL) return fail(RT_ERR_INVALID, "too many tiles");
     p.tiles_z = (int)tiles_z;
     p.tiles_x = (int)tiles_x;
+    {
+        const long long macro_rows = (tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
+        const int permille = s->first_row_permille >= 0 ? s->first_row_permille : horizon_start(s, cam);
+        p.first_macro_row = (int)std::min(macro_rows - 1, macro_rows * (long long)permille / 1000);
+        if (p.first_macro_row < 0) p.first_macro_row = 0;
+    }
     p.n_tiles = (int)n_tiles;
     const int waves_per_block = block / 64;
     const long long blocks_all = (n_tiles + waves_per_block - 1) / waves_per_block;
@@ -888,6 +928,11 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "stack")) {
         if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "stack must be 0 (auto), 1 (LDS) or 2 (HBM)");
         s->stack_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "first_row")) {
+        if (value < -1 || value > 999) return fail(RT_ERR_INVALID, "first_row is in thousandths of the image height, [0, 999], or -1 (automatic)");
+        s->first_row_permille = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "grid_mult")) {

@@ -894,8 +894,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     /* ask for the following tile now; the answer is only needed after this one is rendered */
     if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
     const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
-    const int macro_row = macro / p.tiles_x;
-    const int tile_col = macro - macro_row * p.tiles_x;
+    const int queued_row = macro / p.tiles_x;
+    const int tile_col = macro - queued_row * p.tiles_x;
+    const int shifted_row = queued_row + p.first_macro_row;                         /* first_macro_row < macro_rows */
+    const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : shifted_row;
     const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
     if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */

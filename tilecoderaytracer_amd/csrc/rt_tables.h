@@ -128,6 +128,7 @@ typedef struct RtParams {
     int32_t tiles_x;                     /* wavefront tiles along x */
     int32_t n_tiles;                     /* total wavefront tiles   */
     int32_t stack_in_lds;                /* bounce stack in LDS (behind the tables) instead of HBM */
+    int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around */
 } RtParams;
 
 #endif /* RT_TABLES_H_ */
