@@ -222,14 +222,47 @@ def test_4096_builtin_depth4_properties(oracle):
     assert np.isfinite(img).all() and img.max() > 1.0
 
 
+def _oracle_columns(oracle, make_scene, W, H, depth, columns, threads=8):
+    """{x: oracle column x} rendered by a few threads (the C oracle releases the GIL; one scene per thread)."""
+    from concurrent.futures import ThreadPoolExecutor
+    columns = list(columns)
+    chunks = [columns[i::threads] for i in range(threads) if columns[i::threads]]
+
+    def work(xs):
+        scene = make_scene()
+        return {x: scene.render(W, H, depth, x, x + 1) for x in xs}
+
+    out = {}
+    with ThreadPoolExecutor(max_workers=len(chunks)) as pool:
+        for part in pool.map(work, chunks):
+            out.update(part)
+    return out
+
+
+def test_4096_builtin_depth4_every_pixel(oracle):
+    """configs[1], the bench workload, compared with the oracle pixel for pixel (16.7 M pixels)."""
+    img = Renderer(HostScene.builtin()).render(4096, 4096, 4)
+    from concurrent.futures import ThreadPoolExecutor
+    bounds = [(k * 256, (k + 1) * 256) for k in range(16)]
+
+    def work(b):
+        return oracle.OracleScene.builtin().render(4096, 4096, 4, b[0], b[1])
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        for (x0, x1), want in zip(bounds, pool.map(work, bounds)):
+            assert_same(img[x0:x1], want, f"columns {x0}:{x1}")
+
+
 def test_4096_grid32_depth4_columns(oracle):
     """configs[2] at full size: sampled columns against the oracle + the 64x64 subsample."""
     r = Renderer(HostScene.grid(32, True))
     img = r.render(4096, 4096, 4)
     orc = oracle.OracleScene.grid(32, True)
     assert_same(np.ascontiguousarray(img[::64, ::64]), orc.render(64, 64, 4), "stride-64 subsample")
-    for x0 in (777, 2049):
-        assert_same(img[x0:x0 + 1], orc.render(4096, 4096, 4, x0, x0 + 1), f"column {x0}")
+    # whole columns: every row of them, the horizon rows (far hit points, DESIGN.md section 4) included
+    cols = sorted(set([777, 2049] + list(range(5, 4096, 131))))
+    for x0, want in _oracle_columns(oracle, lambda: oracle.OracleScene.grid(32, True), 4096, 4096, 4, cols).items():
+        assert_same(img[x0:x0 + 1], want, f"column {x0}")
 
 
 def test_4096_grid16_depth8_columns(oracle):
@@ -238,8 +271,9 @@ def test_4096_grid16_depth8_columns(oracle):
     img = r.render(4096, 4096, 8)
     orc = oracle.OracleScene.grid(16, True)
     assert_same(np.ascontiguousarray(img[::64, ::64]), orc.render(64, 64, 8), "stride-64 subsample")
-    for x0 in (123, 3001):
-        assert_same(img[x0:x0 + 1], orc.render(4096, 4096, 8, x0, x0 + 1), f"column {x0}")
+    cols = sorted(set([123, 3001] + list(range(17, 4096, 257))))
+    for x0, want in _oracle_columns(oracle, lambda: oracle.OracleScene.grid(16, True), 4096, 4096, 8, cols).items():
+        assert_same(img[x0:x0 + 1], want, f"column {x0}")
 
 
 def test_render_device_into_torch_memory(oracle):
