@@ -9,7 +9,8 @@
  * for a 4096 x 4096 image.  Here "%f" of a float is produced by exact integer
  * arithmetic (a float times 10^6 fits 64 bits once shifted), rounded half to
  * even exactly like glibc's printf, into a large buffer; values outside the
- * fast range (|v| >= 2^39, inf, nan) fall back to snprintf.  The bytes are
+ * fast range (|v| >= 2^39, inf, nan) fall back to snprintf; blocks of pixels
+ * are formatted by up to 16 threads and written in order.  The bytes are
  * identical to the reference's (tests/test_screen_txt.py).
  */
 #ifndef SCREEN_TXT_HPP_
@@ -17,7 +18,10 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <vector>
 
 namespace celio_txt {
@@ -83,23 +87,43 @@ inline int celio_write_screen_txt(const char *path, int W, int H, const float *r
     std::fprintf(f, "us/pixel:%f.\n", us_per_pixel);
     std::fprintf(f, "filename:%s.\n", "raytracer_screen.txt");
 
-    const size_t kFlush = 4u << 20;
-    std::vector<char> buf(kFlush + 256);
-    char *p = buf.data();
+    /* Pixel lines: blocks of pixels are formatted by a few threads at a time, each
+     * into its own buffer (a line is at most 3 x 48 + 8 bytes), and written in
+     * order; formatting, not the file system, is what takes the time. */
     const size_t n_pixels = (size_t)W * (size_t)H;
+    const size_t kBlock = 1u << 17;                           /* pixels per block, ~4 MB of text */
+    const size_t kLineMax = 3 * 48 + 8;
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (n_threads == 0) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    const size_t n_blocks = (n_pixels + kBlock - 1) / kBlock;
+    if (n_blocks < n_threads) n_threads = n_blocks ? (unsigned)n_blocks : 1u;
+    std::vector<std::unique_ptr<char[]>> bufs(n_threads);       /* uninitialised: only the bytes written get touched */
+    for (auto &b : bufs) b.reset(new char[kBlock * kLineMax]);
+    std::vector<size_t> used(n_threads, 0);
     int rc = 0;
-    for (size_t i = 0; i < n_pixels; ++i) {
-        const float *px = rgb + i * 3;
-        *p++ = '(';
-        p = celio_txt::format_f(p, px[0]); *p++ = ','; *p++ = ' ';
-        p = celio_txt::format_f(p, px[1]); *p++ = ','; *p++ = ' ';
-        p = celio_txt::format_f(p, px[2]); *p++ = ')'; *p++ = '\n';
-        if ((size_t)(p - buf.data()) >= kFlush) {
-            if (std::fwrite(buf.data(), 1, (size_t)(p - buf.data()), f) != (size_t)(p - buf.data())) rc = 1;
-            p = buf.data();
+    auto format_block = [&](unsigned slot, size_t first, size_t last) {
+        char *const start = bufs[slot].get();
+        char *p = start;
+        for (size_t i = first; i < last; ++i) {
+            const float *px = rgb + i * 3;
+            *p++ = '(';
+            p = celio_txt::format_f(p, px[0]); *p++ = ','; *p++ = ' ';
+            p = celio_txt::format_f(p, px[1]); *p++ = ','; *p++ = ' ';
+            p = celio_txt::format_f(p, px[2]); *p++ = ')'; *p++ = '\n';
         }
+        used[slot] = (size_t)(p - start);
+    };
+    for (size_t b0 = 0; b0 < n_blocks; b0 += n_threads) {
+        const unsigned in_round = (unsigned)std::min<size_t>(n_threads, n_blocks - b0);
+        std::vector<std::thread> workers;
+        for (unsigned t = 1; t < in_round; ++t)
+            workers.emplace_back(format_block, t, (b0 + t) * kBlock, std::min(n_pixels, (b0 + t + 1) * kBlock));
+        format_block(0, b0 * kBlock, std::min(n_pixels, (b0 + 1) * kBlock));
+        for (std::thread &w : workers) w.join();
+        for (unsigned t = 0; t < in_round; ++t)
+            if (std::fwrite(bufs[t].get(), 1, used[t], f) != used[t]) rc = 1;
     }
-    if (p != buf.data() && std::fwrite(buf.data(), 1, (size_t)(p - buf.data()), f) != (size_t)(p - buf.data())) rc = 1;
     if (std::fclose(f)) rc = 1;
     return rc;
 }
