@@ -655,10 +655,20 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
  * its size covers the sphere routine's distance-dependent slack, see
  * box_needed()).  A NaN bound compares "overlapping".  Blocking is a boolean OR,
  * so order does not matter. */
+/* Centre and half-extent of the box [lo, hi] of a bounce level's shading points
+ * (the half-extent rounded up so that [c - e, c + e] really covers the box), as
+ * scalars: what every light's shadow scan of that level starts from. */
+__device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V3 *centre, V3 *half) {
+    const V3 c = mk(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+    *half = mk(uniform_f(fmaxf(hi.x - c.x, c.x - lo.x) * 1.000001f), uniform_f(fmaxf(hi.y - c.y, c.y - lo.y) * 1.000001f),
+               uniform_f(fmaxf(hi.z - c.z, c.z - lo.z) * 1.000001f));
+    *centre = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
+}
+
 template <bool kStats>
 __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
-                                         const V3 origins_lo, const V3 origins_hi, Stats<kStats> &st) {
+                                         const V3 origins_centre, const V3 origins_half, Stats<kStats> &st) {
     bool blocked = !active;
     int stat_my_leaves = 0;
     if (p.n_shadow_items == 0) return false;
@@ -671,18 +681,13 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
      * An item can matter only if its box, grown by e (and the rounding slack),
      * meets that centre segment for some s in [0, 1]: a slab test per item-lane. */
     const bool cull = p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS;
-    V3 c = mk(0, 0, 0), e = c, sinv = c;     /* e: half-extent plus slack */
+    const V3 c = origins_centre;             /* both from shading_point_bundle(), once per bounce level */
+    V3 e = origins_half, sinv = mk(0, 0, 0); /* e: half-extent, plus slack below */
     if (cull) {
-        float grow;
-        c = mk(0.5f * (origins_lo.x + origins_hi.x), 0.5f * (origins_lo.y + origins_hi.y), 0.5f * (origins_lo.z + origins_hi.z));
-        /* half-extent, rounded up so that [c - e, c + e] really covers the origin box */
-        e = mk(fmaxf(origins_hi.x - c.x, c.x - origins_lo.x) * 1.000001f, fmaxf(origins_hi.y - c.y, c.y - origins_lo.y) * 1.000001f,
-               fmaxf(origins_hi.z - c.z, c.z - origins_lo.z) * 1.000001f);
         const V3 seg = sub3(light, c);
         sinv = approx_inverse(seg);
-        grow = RT_SPHERE_SLACK * ((fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z)) + 1.0e-4f;
-        /* all of these are the same in every lane: keep them in scalar registers */
-        c = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
+        const float grow = RT_SPHERE_SLACK * ((fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z)) + 1.0e-4f;
+        /* the same in every lane: keep them in scalar registers */
         e = mk(uniform_f(e.x + grow), uniform_f(e.y + grow), uniform_f(e.z + grow));
         sinv = mk(uniform_f(sinv.x), uniform_f(sinv.y), uniform_f(sinv.z));
     }
@@ -1014,7 +1019,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 wave_bounds3(P, shade, &box_lo, &box_hi);
 #endif
             }
-            const V3 plo = box_lo, phi = box_hi;
+            V3 bundle_centre = mk(0, 0, 0), bundle_half = bundle_centre;
+            if (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
@@ -1023,7 +1029,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
-                const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), plo, phi, st);
+                const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
                     /* the winner's material, re-read here rather than kept in registers across the shadow scan */
