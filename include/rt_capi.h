@@ -168,7 +168,7 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
 
 /* Tuning knobs (speed only, never results).  key:
  *   "tile_z"        wavefront tile height, 1,2,4,...,64 (width = 64 / height)
- *   "block_threads" 0 = auto, else 64..1024
+ *   "block_threads" 0 = auto, else 64, 128, 192 or 256
  *   "stack"         bounce stack: 0 auto, 1 LDS, 2 HBM
  *   "grid_mult"     persistent grid = occupancy x CUs x this; 0 = no persistence
  *   "first_row"     where the tile queues start, thousandths of the image
