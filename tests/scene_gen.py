@@ -57,3 +57,38 @@ def build_random(scene, seed, n_spheres=12, n_finite=6, n_infinite=2, n_lights=2
     if two_mirror_camera:
         scene.camera_two_mirrors()
     return scene
+
+
+def build_sphere_field(scene, seed, n_spheres=120, spread=60.0):
+    """A run of consecutive spheres (long enough to be clustered by the kernel),
+    of very different sizes and partly overlapping, over a reflective infinite
+    ground and under a second, slightly tilted infinite plane, seen by the
+    horizontal two-mirrors camera: the horizon rows hit the planes thousands of
+    units away, from where shadow rays graze the whole field -- the regime in
+    which the reference's float sphere test is coarse."""
+    rng = np.random.RandomState(seed)
+    for k in range(2):
+        i = scene.add_sphere((f32(rng.uniform(-20, 20)), f32(rng.uniform(5, spread)), f32(rng.uniform(6, 11.5))), f32(0.15))
+        scene.set_light(i)
+        scene.set_intensity(i, f32(rng.uniform(0.5, 1.0)))
+    g = scene.add_infinite_plane((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+    scene.set_reflective(g, 0.5)
+    scene.set_diffuse(g, 0.5)
+    scene.set_checkerboard(g, (1, 1, 1), (0, 0, 0), f32(rng.uniform(1, 5)), f32(rng.uniform(1, 5)))
+    for k in range(n_spheres):
+        r = f32(rng.choice([0.2, 0.5, 1.0, 1.0, 2.0, 3.5]))
+        i = scene.add_sphere((f32(rng.uniform(-spread / 2, spread / 2)), f32(rng.uniform(4, spread)),
+                              f32(rng.uniform(0.0, 4.0))), r)
+        scene.set_color(i, PALETTE[rng.randint(len(PALETTE))])
+        u = rng.rand()
+        if u < 0.4:
+            scene.set_reflective(i, f32(rng.choice([0.5, 1.0])))
+            scene.set_diffuse(i, f32(rng.choice([0.0, 0.5])))
+        elif u < 0.7:
+            scene.set_specular(i, f32(rng.uniform(0, 1)))
+    c = scene.add_infinite_plane((0.0, 0.0, 12.0), (0.0, f32(rng.uniform(-0.02, 0.02)), -1.0), (1.0, 0.0, 0.0))
+    scene.set_reflective(c, 0.5)
+    scene.set_specular(c, 0.5)
+    scene.set_object_indices(0, 1)
+    scene.camera_two_mirrors()
+    return scene

@@ -407,6 +407,22 @@ def test_more_random_scenes(oracle, seed):
     assert_same(Renderer(host).render(64, 48, 6), orc.render(64, 48, 6), f"seed {seed}")
 
 
+@pytest.mark.parametrize("seed,n", [(1, 64), (2, 120), (3, 200), (4, 333), (5, 90), (6, 150)])
+def test_random_sphere_fields(oracle, seed, n):
+    """Clustered sphere runs of mixed sizes seen to the horizon (far hit points)."""
+    from scene_gen import build_sphere_field
+    host = build_sphere_field(HostScene.empty(), seed, n_spheres=n)
+    orc = build_sphere_field(oracle.OracleScene(), seed, n_spheres=n)
+    r = Renderer(host)
+    assert_same(r.render(96, 80, 4), orc.render(96, 80, 4), f"field {seed}")
+    # the rows around the horizon at a finer pitch: rows 2040..2055 of a 4096-row image, 48 columns
+    W, H = 48, 4096
+    img = r.render(W, H, 3)
+    want = orc.render(W, H, 3)
+    assert_same(img[:, 2040:2056], want[:, 2040:2056], f"field {seed} horizon rows")
+    assert_same(img, want, f"field {seed} tall strip")
+
+
 def test_counting_build_matches_and_counts(oracle):
     r = Renderer(HostScene.builtin())
     img, st = r.render_stats(64, 64, 3)
