@@ -246,13 +246,6 @@ __device__ __forceinline__ void aa_rectangle_distance(const float4 r0, const flo
 #define RT_SPHERE_SLACK 1.5e-3f
 #endif
 
-/* (v[axis], v[axis+1], v[axis+2]), indices mod 3, for a wave-uniform axis */
-__device__ __forceinline__ V3 rotate_axes(const V3 v, const int axis) {
-    if (axis == 0) return v;
-    if (axis == 1) return mk(v.y, v.z, v.x);
-    return mk(v.z, v.x, v.y);
-}
-
 __device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
     /* a NaN or infinity in any component makes the sum non-finite */
     return isfinite((fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)));
@@ -626,7 +619,10 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 3 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 const int axis = kind - RT_KIND_FINITE_AA;             /* of the normal; the record is in cyclic order from it */
-                aa_rectangle_distance(g[0], g[1], rotate_axes(o, axis), rotate_axes(d, axis), best, &hit, &t);
+                /* one copy of the test per axis: the rotation costs nothing then (six moves otherwise) */
+                if (axis == 0)      aa_rectangle_distance(g[0], g[1], mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), best, &hit, &t);
+                else if (axis == 1) aa_rectangle_distance(g[0], g[1], mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), best, &hit, &t);
+                else                aa_rectangle_distance(g[0], g[1], mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), best, &hit, &t);
                 if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
@@ -767,7 +763,10 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
             } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 3 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 const int axis = kind - RT_KIND_FINITE_AA;
-                aa_rectangle_distance(g[0], g[1], rotate_axes(o, axis), rotate_axes(d, axis), dist_to_light, &hit, &t);
+                /* one copy of the test per axis: the rotation costs nothing then (six moves otherwise) */
+                if (axis == 0)      aa_rectangle_distance(g[0], g[1], mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), dist_to_light, &hit, &t);
+                else if (axis == 1) aa_rectangle_distance(g[0], g[1], mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), dist_to_light, &hit, &t);
+                else                aa_rectangle_distance(g[0], g[1], mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), dist_to_light, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
