@@ -11,7 +11,13 @@ block), every rank renders its strip into HBM and the strips are gathered to
 rank 0 with RCCL (torch.distributed backend "nccl") -- STRONG scaling: the
 image is fixed, the work per GPU shrinks.  Frames are independent, so the
 gather of frame k (RCCL's stream) overlaps the render of frame k+1 (two strip
-buffers; --no-overlap serialises them).
+buffers; --no-overlap serialises them).  The strips are cut by measured cost
+(--partition balanced, the default): the first two of the W warm-up steps run
+N equal strips and measure every rank's kernel time and the time of a gather
+on its own; the image is then re-cut so that rank 0 -- which receives and sends
+nothing -- renders as long as a peer needs to render and ship its columns
+(tilecoderaytracer_amd/distributed.py: balanced_bounds).  All W warm-up steps
+are untimed; the K timed steps all run the final partition.
 
 Timed region: barrier + synchronize, K steps (kernel + gather), barrier +
 synchronize; MAX over ranks.  The framebuffer stays in HBM (inputs -- the
@@ -74,6 +80,10 @@ def parse_args():
                     help="rt_set_option tuning knob (speed only), e.g. --option stack=2")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the gather even at N = 1 (exercises the RCCL path on one GPU)")
+    ap.add_argument("--partition", default="balanced", choices=["balanced", "equal"],
+                    help="N > 1: 'balanced' re-cuts the strips from kernel and gather times measured in the first "
+                         "warm-up steps (rank 0, which receives, renders more when a link is slower than a GPU); "
+                         "'equal' keeps N equal strips")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: gather each frame before rendering the next (no render/gather pipelining)")
     return ap.parse_args()
@@ -159,10 +169,12 @@ def main():
     import torch
     import torch.distributed as dist
     from tilecoderaytracer_amd import HostScene, Renderer
-    from tilecoderaytracer_amd.distributed import StripPipeline
+    from tilecoderaytracer_amd.distributed import StripPipeline, measure_and_balance
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
+    if os.environ.get("TCRT_BENCH_ONE_DEVICE"):        # testing aid: every rank on device 0 (if the RCCL build allows it)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -196,9 +208,14 @@ def main():
         for kv in args.option:
             k, v = kv.split("=")
             renderer.set_option(k, int(v))
-        pipe = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap, force_gather=args.force_dist)
-        x0, x1 = pipe.x0, pipe.x1
-        pipe.render = lambda buf: renderer.render_device(W, H, depth, x0, x1, buf.data_ptr(), stream)
+        def make_pipe(bounds=None):
+            pp = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap,
+                               force_gather=args.force_dist, bounds=bounds)
+            a, b = pp.x0, pp.x1
+            pp.render = lambda buf: renderer.render_device(W, H, depth, a, b, buf.data_ptr(), stream)
+            return pp
+
+        pipe = make_pipe()
 
         def fence():
             pipe.drain()
@@ -206,7 +223,35 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
-        for _ in range(warmup):
+        # N > 1: the first warm-up steps run the equal partition and measure what a balanced one
+        # needs -- every rank's kernel time and the time of the gather alone -- then the strips are
+        # re-cut (tilecoderaytracer_amd.distributed.balanced_bounds) and the warm-up continues.
+        partition_note = None
+        warm_left = warmup
+        if world > 1 and args.partition == "balanced" and warmup >= 3:
+            pipe.step()
+            fence()
+            renderer.reset_timing()
+            pipe.step()
+            fence()
+            tm = renderer.timing()
+            my_kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
+            bounds = None
+            try:
+                bounds, partition_note = measure_and_balance(pipe, W, my_kernel_ms, fence, dev)
+            except Exception as e:                                         # never lose the run to the tuning step
+                partition_note = f"balanced partition unavailable ({e!r}); equal strips"
+            # all ranks take the new strips, or none does
+            ok = torch.tensor([1 if bounds is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 1:
+                pipe = make_pipe(bounds)
+            elif bounds is not None:
+                partition_note = "balanced partition failed on another rank; equal strips"
+            warm_left = warmup - 2
+        x0, x1 = pipe.x0, pipe.x1
+
+        for _ in range(warm_left):
             pipe.step()
         fence()
         renderer.reset_timing()
@@ -217,12 +262,14 @@ def main():
         elapsed = time.perf_counter() - t0
         tm = renderer.timing()
         kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
+        own_kernel_ms = kernel_ms                      # this rank's launches (the roofline pairs it with this rank's pixels)
         if use_dist:
             t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, kernel_ms = float(t[0]), float(t[1])
         return dict(scene_name=scene_name, W=W, H=H, depth=depth, cfg_note=cfg_note, host=host, renderer=renderer,
-                    x0=x0, x1=x1, strip=pipe.strip, elapsed=elapsed, kernel_ms=kernel_ms)
+                    x0=x0, x1=x1, strip=pipe.strip, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=kernel_ms,
+                    partition=pipe.describe(), partition_note=partition_note)
 
     m = measure(args.workload, args.steps, args.warmup, args.size)
     scene_name, W, H, depth, cfg_note = m["scene_name"], m["W"], m["H"], m["depth"], m["cfg_note"]
@@ -234,7 +281,7 @@ def main():
     grid = None
     if args.workload == "builtin" and not args.size and not args.no_extra:
         g_steps = max(3, args.steps // 5)
-        g = measure("grid32", g_steps, 2)
+        g = measure("grid32", g_steps, 4 if world > 1 else 2)
         grid = {
             "workload": f"{g['scene_name']} scene, {g['W']}x{g['H']}, max depth {g['depth']}",
             "baseline_config": g["cfg_note"],
@@ -243,6 +290,7 @@ def main():
             "steps": g_steps,
             "ms_per_step": round(g["elapsed"] / g_steps * 1e3, 4),
             "kernel_ms": round(g["kernel_ms"], 4),
+            "partition": g["partition"],
         }
 
     if rank == 0:
@@ -274,9 +322,10 @@ def main():
                 "workload": f"{scene_name} scene, {W}x{H}, max depth {depth}",
                 "baseline_config": cfg_note,
                 "objects": host.object_count,
-                "partition": f"{world} x-strip(s) of {strip} columns" + (
+                "partition": m["partition"] + (
                     ", RCCL gather to rank 0" + ("" if args.no_overlap else ", gather of frame k overlapped with render of frame k+1")
                     if world > 1 else ""),
+                "partition_note": m["partition_note"],
                 "block_threads": li.block_threads,
                 "lds_bytes_per_block": li.lds_bytes,
                 "wave_tile": f"{li.tile_x}x{li.tile_z}",

@@ -98,3 +98,124 @@ def test_strip_bounds_cover_the_image_exactly():
                 assert 0 <= x0 <= x1 <= W and x1 - x0 <= strip
                 cols += list(range(x0, x1))
             assert cols == list(range(W))
+
+
+def test_balanced_bounds_properties():
+    from tilecoderaytracer_amd.distributed import balanced_bounds, equal_bounds
+    rng = np.random.RandomState(7)
+    for W in (8, 37, 4096):
+        for world in (1, 2, 3, 8):
+            for cost in (np.full(W, 1.0 / W), rng.uniform(0.1, 2.0, W), np.r_[np.zeros(W // 2), np.ones(W - W // 2)]):
+                for send in (0.0, 0.5 * cost.mean(), 3.0 * cost.mean()):
+                    b = balanced_bounds(W, world, cost, send)
+                    assert len(b) == world and b[0][0] == 0 and b[-1][1] == W
+                    assert all(0 <= x0 <= x1 <= W for x0, x1 in b)
+                    assert all(b[r][1] == b[r + 1][0] for r in range(world - 1))
+    # nothing to send and a flat cost: the equal partition
+    assert balanced_bounds(4096, 8, np.full(4096, 1.0), 0.0) == equal_bounds(4096, 8)
+    # a link slower than a GPU: the receiver renders more, the peers share the rest evenly
+    b = balanced_bounds(4096, 8, np.full(4096, 1.08 / 4096), 2.68 / 4096)
+    widths = [x1 - x0 for x0, x1 in b]
+    assert widths[0] > 2 * widths[1] and max(widths[1:]) - min(widths[1:]) <= 8
+    frame = max([widths[0] * 1.08 / 4096] + [w * 2.68 / 4096 for w in widths[1:]])
+    assert frame < 0.30                                       # 0.335 with equal strips
+    # a costly middle: strips there get narrower
+    cost = np.ones(4096)
+    cost[1536:2560] = 4.0
+    widths = [x1 - x0 for x0, x1 in balanced_bounds(4096, 8, cost, 0.0)]
+    assert min(widths) < 300 and max(widths) > 600
+
+
+def _uneven_worker(rank, world, W, H, bounds, init_file, out_file, overlap):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle_lib
+    from tilecoderaytracer_amd.distributed import StripPipeline
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    scene = oracle_lib.OracleScene.builtin()
+    frame = {"d": 0}
+
+    def render(buf):
+        x0, x1 = pipe.x0, pipe.x1
+        if x1 > x0:
+            buf[: x1 - x0] = torch.from_numpy(scene.render(W, H, frame["d"] % 3, x0, x1))
+        frame["d"] += 1
+
+    pipe = StripPipeline(W, H, world, rank, "cpu", render, overlap=overlap, bounds=bounds)
+    assert (pipe.x0, pipe.x1) == tuple(bounds[rank])
+    for _ in range(5):
+        pipe.step()
+    img = pipe.image(W)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_file, img.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("bounds", [[(0, 20), (20, 25), (25, 30)], [(0, 11), (11, 11), (11, 30)], [(0, 0), (0, 17), (17, 30)]])
+def test_uneven_strips_reach_rank0_in_place(oracle, bounds, overlap):
+    """The measured-cost partition: strips of different widths (one may be empty, rank 0's too),
+    sent point-to-point into rank 0's image; five pipelined frames, the last one must be whole."""
+    world, W, H = 3, 30, 12
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.npy")
+        mp.spawn(_uneven_worker, args=(world, W, H, bounds, init_file, out_file, overlap), nprocs=world, join=True)
+        got = np.load(out_file)
+    ref = oracle.OracleScene.builtin().render(W, H, 4 % 3)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def _balance_worker(rank, world, W, H, init_file, out_file):
+    """bench.py's N > 1 warm-up: equal partition, measure, re-cut, carry on."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import json
+    import oracle_lib
+    from tilecoderaytracer_amd.distributed import StripPipeline, measure_and_balance
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    scene = oracle_lib.OracleScene.builtin()
+
+    def make(bounds=None):
+        pp = StripPipeline(W, H, world, rank, "cpu", None, overlap=True, bounds=bounds)
+
+        def render(buf, pp=pp):
+            if pp.x1 > pp.x0:
+                buf[: pp.x1 - pp.x0] = torch.from_numpy(scene.render(W, H, 2, pp.x0, pp.x1))
+        pp.render = render
+        return pp
+
+    pipe = make()
+
+    def sync():
+        pipe.drain()
+        dist.barrier()
+
+    pipe.step()
+    pipe.step()
+    fake_kernel_ms = [1.0, 3.0, 1.0][rank]               # the middle strip is the expensive one
+    bounds, note = measure_and_balance(pipe, W, fake_kernel_ms, sync, "cpu")
+    pipe = make(bounds)
+    for _ in range(3):
+        pipe.step()
+    img = pipe.image(W)
+    dist.barrier()
+    json.dump({"bounds": bounds, "note": note}, open(f"{out_file}.{rank}.json", "w"))
+    if rank == 0:
+        np.save(out_file, img.numpy())
+    dist.destroy_process_group()
+
+
+def test_measured_partition_is_agreed_on_and_delivers_the_image(oracle):
+    import json
+    world, W, H = 3, 48, 10
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.npy")
+        mp.spawn(_balance_worker, args=(world, W, H, init_file, out_file), nprocs=world, join=True)
+        got = np.load(out_file)
+        per_rank = [json.load(open(f"{out_file}.{r}.json")) for r in range(world)]
+    assert per_rank[0]["bounds"] == per_rank[1]["bounds"] == per_rank[2]["bounds"]
+    b = per_rank[0]["bounds"]
+    assert b[0][0] == 0 and b[-1][1] == W and (b[1][1] - b[1][0]) < 16      # the costly strip got narrower
+    ref = oracle.OracleScene.builtin().render(W, H, 2)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
