@@ -366,7 +366,7 @@ int pack_scene(rt_scene *s) {
     if (!cidx.empty()) std::memcpy(s->image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
 
     /* Item tables (rt_tables.h): one item per object that is not part of a clustered run, in
-     * Scene order, then one per group of each clustered run.  `near_items` covers every object,
+     * Scene order, then one per leaf (or group) of each clustered run.  `near_items` covers every object,
      * `shadow_items` the non-light objects of the shadow scan range. */
     {
         const float INF = INFINITY;

@@ -45,12 +45,16 @@
  * (src/RayTracer.cpp:50-89) and the shadow scan over the non-light objects of
  * the scan range (src/RayTracer.cpp:709-739) -- walk a table of ITEMS: one per
  * object that is not in a clustered run, in Scene index order, then one per
- * group of each clustered run.  2 quads per item:
+ * LEAF of each clustered run (or, with the "leaf_items" option off, one per
+ * group).  2 quads per item:
  *   {box lo.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
  *   {box hi.xyz, bits(Scene index | quad offset of the full 5-quad plane record << 12)}
  * kind = RT_KIND_SPHERE / _INFINITE_PLANE / _FINITE_PLANE;
  *        RT_KIND_FINITE_AA + normal axis for an axis-aligned rectangle (geometry
  *        offset = its aa record);
+ *        RT_KIND_SPHERE_LEAF for a leaf (count = its members, geometry offset =
+ *        its first member sphere, second word = u32 index of its members'
+ *        Scene indices);
  *        RT_KIND_SPHERE_CLUSTERED for a group (count = its leaves, geometry
  *        offset = its first leaf record, second word = u32 index of the run's
  *        cidx table).
@@ -97,7 +101,9 @@
  * a macro tile is RT_MACRO_ROWS vertically adjacent wavefront tiles */
 #define RT_TILE_QUEUES 8
 #define RT_QUEUE_STRIDE 32
+#ifndef RT_MACRO_ROWS
 #define RT_MACRO_ROWS 4
+#endif
 #define RT_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)   /* s_getreg_b32 HW_REG_XCC_ID, bits [3:0] */
 
 #define RT_NEAR_CULL_MIN_ITEMS 8     /* below this many items the nearest scan skips the bundle cull */
