@@ -1,0 +1,40 @@
+"""Randomised parity sweep, GPU kernel vs CPU oracle (development aid; the permanent cases live in tests/).
+
+usage: fuzz_gpu.py [first_seed=1000] [count=200]"""
+import os, sys, time
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+sys.path.insert(0, os.path.join(R, "tests"))
+import oracle_lib                                   # noqa: E402
+from scene_gen import build_random, build_sphere_field   # noqa: E402
+from tilecoderaytracer_amd import HostScene, Renderer    # noqa: E402
+
+kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+first, count = int(kv.get("first_seed", 1000)), int(kv.get("count", 200))
+bad, t0 = [], time.time()
+for seed in range(first, first + count):
+    rng = np.random.RandomState(seed)
+    if seed % 4 == 0:
+        n = int(rng.choice([64, 80, 130, 260]))
+        mk = lambda s: build_sphere_field(s, seed, n_spheres=n, spread=float(rng.choice([30.0, 60.0, 200.0])))
+        W, H, depth = 40, int(rng.choice([64, 512, 2048])), int(rng.randint(1, 6))
+    else:
+        kw = dict(n_spheres=int(rng.randint(0, 40)), n_finite=int(rng.randint(0, 12)), n_infinite=int(rng.randint(0, 3)),
+                  n_lights=int(rng.randint(1, 4)), shadows=bool(rng.rand() < 0.8))
+        mk = lambda s: build_random(s, seed, **kw)
+        W, H, depth = int(rng.randint(1, 90)), int(rng.randint(1, 90)), int(rng.randint(0, 9))
+    state = rng.get_state()
+    host = mk(HostScene.empty())
+    rng.set_state(state)
+    orc = mk(oracle_lib.OracleScene())
+    r = Renderer(host)
+    if seed % 3 == 0:
+        r.set_option("tile_z", int(2 ** rng.randint(0, 7)))
+    got, want = r.render(W, H, depth), orc.render(W, H, depth)
+    if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+        d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        bad.append((seed, W, H, depth, len(d), d[0].tolist()))
+        print("MISMATCH", bad[-1], flush=True)
+print(f"{count} scenes from seed {first}: {len(bad)} mismatching, {time.time() - t0:.1f} s", flush=True)
+sys.exit(1 if bad else 0)
