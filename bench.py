@@ -12,9 +12,9 @@ rank 0 with RCCL (torch.distributed backend "nccl") -- STRONG scaling: the
 image is fixed, the work per GPU shrinks.  Frames are independent, so the
 gather of frame k (RCCL's stream) overlaps the render of frame k+1 (two strip
 buffers; --no-overlap serialises them).  The strips are cut by measured cost
-(--partition balanced, the default): the first two of the W warm-up steps run
-N equal strips and measure every rank's kernel time and the time of a gather
-on its own; the image is then re-cut so that rank 0 -- which receives and sends
+(--partition balanced, the default): the first two warm-up steps (two extra
+untimed ones if W < 3) run N equal strips and measure every rank's kernel time
+and the time of a gather on its own; the image is then re-cut so that rank 0 -- which receives and sends
 nothing -- renders as long as a peer needs to render and ship its columns
 (tilecoderaytracer_amd/distributed.py: balanced_bounds).  All W warm-up steps
 are untimed; the K timed steps all run the final partition.
@@ -228,7 +228,7 @@ def main():
         # re-cut (tilecoderaytracer_amd.distributed.balanced_bounds) and the warm-up continues.
         partition_note = None
         warm_left = warmup
-        if world > 1 and args.partition == "balanced" and warmup >= 3:
+        if world > 1 and args.partition == "balanced":
             pipe.step()
             fence()
             renderer.reset_timing()
@@ -248,7 +248,7 @@ def main():
                 pipe = make_pipe(bounds)
             elif bounds is not None:
                 partition_note = "balanced partition failed on another rank; equal strips"
-            warm_left = warmup - 2
+            warm_left = max(warmup - 2, 1)       # at least one untimed frame on the final partition (first use of the links)
         x0, x1 = pipe.x0, pipe.x1
 
         for _ in range(warm_left):
