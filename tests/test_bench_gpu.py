@@ -1,0 +1,36 @@
+"""bench.py's contract, checked on the GPU box: exactly one JSON line on stdout with
+the fields the driver reads, the roofline and cpu_baseline objects included."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--cpu-sample-columns", "64"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["unit"] == "Mrays/s" and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 1000.0                                  # the north star's target was 100 Mrays/s
+    assert abs(j["value"] - 4096 * 4096 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert r["algorithmic_bytes_per_launch"] == 4096 * 4096 * 12
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert j["sphere_grid"]["value"] > 100.0
