@@ -421,6 +421,27 @@ def test_more_random_scenes(oracle, seed):
     assert_same(Renderer(host).render(64, 48, 6), orc.render(64, 48, 6), f"seed {seed}")
 
 
+def test_degenerate_geometry(oracle):
+    """Zero and negative radii, a plane with a zero normal (its normalisation divides by
+    zero), a rectangle of zero width, the camera inside a mirror sphere: whatever the
+    reference's arithmetic makes of them, the kernel must make the same."""
+    host, orc = HostScene.empty(), oracle.OracleScene()
+    for s in (host, orc):
+        i = s.add_sphere((3.0, 5.0, 8.0), 0.15)
+        s.set_light(i)
+        s.add_sphere((0.0, 6.0, 1.0), 0.0)
+        s.add_sphere((1.0, 6.0, 1.0), -1.0)
+        s.add_infinite_plane((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 0.0, 0.0))
+        s.add_finite_plane_axes((0.0, 8.0, 0.0), (0.0, -1.0, 0.0), (1.0, 0.0, 0.0), 0.0, 3.0)
+        i = s.add_infinite_plane((0.0, 0.0, -1.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+        s.set_reflective(i, 0.5)
+        i = s.add_sphere((0.0, -1.0, 2.5), 3.0)
+        s.set_reflective(i, 1.0)
+        s.set_object_indices(0, 1)
+        s.camera_two_mirrors()
+    assert_same(Renderer(host).render(48, 40, 4), orc.render(48, 40, 4), "degenerate geometry")
+
+
 @pytest.mark.parametrize("seed,n", [(1, 64), (2, 120), (3, 200), (4, 333), (5, 90), (6, 150)])
 def test_random_sphere_fields(oracle, seed, n):
     """Clustered sphere runs of mixed sizes seen to the horizon (far hit points)."""
