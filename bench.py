@@ -343,7 +343,7 @@ def main():
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels_per_launch,
                 "note": "12 B/pixel framebuffer store is the only HBM traffic that scales with the image; "
-                        "the kernel is fp32-VALU-bound (non-FMA), see DESIGN.md",
+                        "the kernel is bound by fp32 (non-FMA) instruction issue, see DESIGN.md",
             },
         }
         if grid is not None:
