@@ -600,20 +600,29 @@ int horizon_start(const rt_scene *s, const rt_camera_desc *cam) {
     return std::max(0, (int)(best * 1000.0) - 8);
 }
 
-/* Workgroup size and where the bounce stack goes.  The stack (16 B per level
- * per thread) shares LDS with the scene tables when the sum stays within
- * 160 KiB / 6, i.e. six workgroups per CU still fit; otherwise it moves to
- * HBM and the tables alone decide the occupancy. */
-int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, int *stack_in_lds) {
+/* Workgroup size and where the bounce stack goes.  The stack is 16 B per level
+ * per thread.  As many of its lowest levels as fit share LDS with the scene
+ * tables while RT_STACK_LDS_SHARE workgroups per CU still fit in the 160 KiB
+ * (nearly every reflection chain uses the first levels, few the deep ones); the
+ * rest lives in HBM.  Option "stack": 1 = all of it in LDS, 2 = all in HBM. */
+int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, int *stack_lds_levels) {
     const size_t scene_bytes = (size_t)s->base.image_quads * 16;
     if (scene_bytes > RT_MAX_LDS_BYTES) return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
     *block = s->block_threads_opt ? s->block_threads_opt : 256;
-    const double with_stack = (double)scene_bytes + (double)RT_STACK_ENTRY_BYTES * (double)(max_depth + 1) * (double)*block;
-    const bool in_lds = s->stack_opt == 1 || (s->stack_opt == 0 && with_stack <= (double)(RT_MAX_LDS_BYTES / RT_STACK_LDS_SHARE));
-    if (in_lds && with_stack > (double)RT_MAX_LDS_BYTES)
-        return fail(RT_ERR_CAPACITY, "stack option: tables + bounce stack exceed 160 KiB LDS");
-    *stack_in_lds = in_lds ? 1 : 0;
-    *lds_bytes = in_lds ? (int)with_stack : (int)scene_bytes;
+    const double per_level = (double)RT_STACK_ENTRY_BYTES * (double)*block;
+    const double levels = (double)max_depth + 1.0;
+    double in_lds = 0.0;
+    if (s->stack_opt == 1) {
+        in_lds = levels;
+        if ((double)scene_bytes + levels * per_level > (double)RT_MAX_LDS_BYTES)
+            return fail(RT_ERR_CAPACITY, "stack option: tables + bounce stack exceed 160 KiB LDS");
+    } else if (s->stack_opt == 0) {
+        const double room = (double)(RT_MAX_LDS_BYTES / RT_STACK_LDS_SHARE) - (double)scene_bytes;
+        in_lds = room > 0.0 ? std::floor(room / per_level) : 0.0;
+        if (in_lds > levels) in_lds = levels;
+    }
+    *stack_lds_levels = (int)in_lds;
+    *lds_bytes = (int)((double)scene_bytes + in_lds * per_level);
     return RT_OK;
 }
 
@@ -627,8 +636,8 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if ((double)(x1 - x0) * (double)H * 3.0 > 2.0e9 * 4.0)
         return fail(RT_ERR_INVALID, "strip too large");
 
-    int block = 0, lds_bytes = 0, stack_in_lds = 0;
-    int rc = choose_block(s, max_depth, &block, &lds_bytes, &stack_in_lds);
+    int block = 0, lds_bytes = 0, stack_lds_levels = 0;
+    int rc = choose_block(s, max_depth, &block, &lds_bytes, &stack_lds_levels);
     if (rc) return rc;
 
     RtParams p = s->base;
@@ -641,7 +650,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.sw = cam->screen_width; p.sh = cam->screen_height;
     p.shw = cam->screen_halfwidth; p.shh = cam->screen_halfheight;
     p.W = W; p.H = H; p.x0 = x0; p.x1 = x1; p.max_depth = max_depth;
-    p.stack_in_lds = stack_in_lds;
+    p.stack_lds_levels = stack_lds_levels;
     /* Wavefront tile shape (speed only).  4 x 16 (x by z) makes every lane-row's
      * stores whole 64-byte sectors (16 pixels x 12 B = 192 B, aligned): measured
      * WRITE_SIZE = 1.08 x the framebuffer bytes vs 1.27 x for 16 x 4.  On the
@@ -703,7 +712,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     /* bounce stack: one slice per workgroup of the persistent grid */
     {
-        const double need_d = stack_in_lds ? 16.0
+        const double need_d = stack_lds_levels > max_depth ? 16.0
                                            : (double)blocks * (double)block * (double)(max_depth + 1) * RT_STACK_ENTRY_BYTES;
         if (need_d > 8.0e9)
             return fail(RT_ERR_CAPACITY, "max_depth too large: the bounce stack would exceed 8 GB of HBM");

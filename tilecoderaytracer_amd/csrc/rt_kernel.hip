@@ -297,9 +297,9 @@ __device__ __forceinline__ bool box_needed(const float4 b0, const float4 b1, con
  * from it (a per-lane address, an int -> float conversion) is then computed
  * there, instead of being hoisted out of the tile loop into a vector register
  * that lives -- or is spilled -- across the scans. */
-__device__ __forceinline__ int here(int scalar_register_value) {      /* a kernel argument, a workgroup id: already in an SGPR */
-    asm volatile("" : "+s"(scalar_register_value));
-    return scalar_register_value;
+__device__ __forceinline__ int here(int uniform_value) {
+    asm volatile("" : "+v"(uniform_value));          /* opaque, wherever the compiler kept it ... */
+    return __builtin_amdgcn_readfirstlane(uniform_value);   /* ... and scalar again */
 }
 
 __device__ __forceinline__ float uniform_f(const float v) {
@@ -855,11 +855,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     __syncthreads();
 
     /* Bounce stack, [level][threadIdx.x], one 16-byte entry per reflective level
-     * per lane.  It lives in LDS behind the scene tables when that keeps at
-     * least six workgroups per CU (small scenes, moderate depth); otherwise in
-     * this workgroup's slice of an HBM buffer, written and read coalesced, so
-     * that a large scene table alone decides the occupancy. */
-    const bool stack_in_lds = p.stack_in_lds != 0;
+     * per lane.  The lowest levels -- the ones nearly every chain uses -- live in
+     * LDS behind the scene tables, as many as fit while seven workgroups per CU
+     * still do; deeper levels go to this workgroup's slice of an HBM buffer,
+     * written and read coalesced. */
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
 
     /* Self-scheduling (the reference's strategy 2, src/RayTracer.cpp:956-992:
@@ -1081,8 +1080,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 float4 e;
                 e.x = C.x; e.y = C.y; e.z = C.z;
                 e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
-                if (stack_in_lds) lds[here(p.image_quads) + level * blockDim.x + threadIdx.x] = e;
-                else              bounce_stack[hbm_stack_entry(p, level)] = e;
+                if (level < p.stack_lds_levels) lds[here(p.image_quads) + level * blockDim.x + threadIdx.x] = e;
+                else                            bounce_stack[hbm_stack_entry(p, level)] = e;
                 top = level + 1;
                 o = P;
                 d = normalize3(reflected);                   /* Ray(point, reflected) */
@@ -1098,7 +1097,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     /* unwind: final_k = local_k + (rf_k * C_{k+1}) * oc_k, inside-out (:601) */
     for (int k = levels - 1; k >= 0; --k) {
         if (k < top) {
-            const float4 e = stack_in_lds ? lds[here(p.image_quads) + k * blockDim.x + threadIdx.x] : bounce_stack[hbm_stack_entry(p, k)];
+            float4 e;
+            if (k < p.stack_lds_levels) e = lds[here(p.image_quads) + k * blockDim.x + threadIdx.x];
+            else                        e = bounce_stack[hbm_stack_entry(p, k)];
             const uint32_t bits = __float_as_uint(e.w);
             const uint32_t info = lds_u32[p.objinfo_off * 4 + (bits & 0xFFFFu)];
             const int mat = (int)(info >> 20);

@@ -92,7 +92,7 @@
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
 #define RT_MAX_LDS_BYTES  (160 * 1024)
 #ifndef RT_STACK_LDS_SHARE
-#define RT_STACK_LDS_SHARE 6      /* the bounce stack goes to LDS when tables + stack fit this many times per CU */
+#define RT_STACK_LDS_SHARE 7      /* tables + the LDS part of the bounce stack must fit this many times per CU */
 #endif
 
 #define RT_TILE_STATS 6          /* counting build: words per wavefront tile {cycles, sphere tests, box tests, scans, start, end (100 MHz clock)} */
@@ -133,7 +133,7 @@ typedef struct RtParams {
     int32_t tiles_z;                     /* wavefront tiles along z */
     int32_t tiles_x;                     /* wavefront tiles along x */
     int32_t n_tiles;                     /* total wavefront tiles   */
-    int32_t stack_in_lds;                /* bounce stack in LDS (behind the tables) instead of HBM */
+    int32_t stack_lds_levels;            /* bounce levels below this keep their stack entries in LDS (behind the tables), the others in HBM */
     int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around */
 } RtParams;
 
