@@ -35,6 +35,9 @@ Extra objects on the JSON line:
                 1024-sphere grid scene, BASELINE.json configs[2], the scene the
                 north star quotes for the 1/2/4/8-GPU series; a few steps, after
                 and outside the headline timed region.
+  secondary     SURVEY.md 8(d)'s secondary figures from the counting build: all rays
+                per second (primary + reflection + shadow) and intersection tests
+                per second against the plain fp32 VALU peak.
   cpu_baseline  the CPU oracle (oracle/rt_oracle.c, a port of the reference's
                 algorithm; the reference itself is unbuildable here) timed on
                 this host's cores on a bounded sample of the same workload.
@@ -348,6 +351,26 @@ def main():
         }
         if grid is not None:
             out["sphere_grid"] = grid
+        if world == 1 and not args.no_extra:
+            # SURVEY.md 8(d) secondary figures, from the counting build at 1024 x 1024 (per-pixel counts
+            # barely depend on the resolution): all rays traced, and intersection tests against the
+            # non-packed, non-FMA fp32 VALU peak (CUs x 64 lanes x clock; ~15 flop per test)
+            try:
+                _, st = renderer.render_stats(1024, 1024, depth)
+                px = 1024.0 * 1024.0
+                rays_pp = (st["nearest_rays"] + st["shadow_rays"]) / px
+                tests_pp = (st["wave_sphere_tests"] + st["wave_plane_tests"] + st["wave_box_tests"]) * 64.0 / px
+                pixels_per_s = out["value"] * 1e6
+                out["secondary"] = {
+                    "rays_per_pixel": round(rays_pp, 3),
+                    "total_rays_per_s": round(pixels_per_s * rays_pp, 0),
+                    "tests_issued_per_pixel": round(tests_pp, 2),
+                    "tests_per_s": round(pixels_per_s * tests_pp, 0),
+                    "test_flop_frac_of_valu_peak": round(pixels_per_s * tests_pp * 15.0 / (256 * 64 * 2.4e9), 4),
+                    "note": "counting build, 1024x1024; peak = 256 CUs x 64 lanes x 2.4 GHz, one non-fused fp32 op per lane and clock",
+                }
+            except Exception as e:
+                out["secondary_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cols = args.cpu_sample_columns or {"builtin": 4096, "builtin8k": 2048}.get(args.workload, 64)

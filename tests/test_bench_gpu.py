@@ -34,3 +34,6 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert j["sphere_grid"]["value"] > 100.0
+    sec = j["secondary"]
+    assert sec["rays_per_pixel"] > 1.0 and sec["total_rays_per_s"] > j["value"] * 1e6
+    assert 0.0 < sec["test_flop_frac_of_valu_peak"] < 1.0
