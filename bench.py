@@ -49,6 +49,8 @@ import sys
 import threading
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -113,8 +115,10 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(scene_name, W, H, depth, sample_columns):
-    """Time the CPU oracle on all host cores over evenly spread column chunks."""
+def cpu_baseline(scene_name, W, H, depth, sample_columns, gpu_image=None):
+    """Time the CPU oracle on all host cores over evenly spread column chunks; with
+    gpu_image (the GPU's W x H x 3 frame on the host) also compare every sampled
+    column with it -- the "max per-channel delta vs CPU ref" half of the metric."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib  # noqa: E402  (the oracle is the thing timed here, nothing else uses it)
 
@@ -126,11 +130,16 @@ def cpu_baseline(scene_name, W, H, depth, sample_columns):
     scenes = [oracle_lib.OracleScene.named(scene_name) for _ in range(cores)]
     done = [0] * cores
 
+    deltas = [[0.0, 0, 0] for _ in range(cores)]       # per thread: max |d|, pixels > 1e-6, pixels > 1e-4
+    kept = [[] for _ in range(cores)]
+
     def work(t):
         s = scenes[t]
         for k in range(t, n_chunks, cores):
-            s.render(W, H, depth, starts[k], starts[k] + chunk)
+            ref = s.render(W, H, depth, starts[k], starts[k] + chunk)
             done[t] += chunk * H
+            if gpu_image is not None:
+                kept[t].append((starts[k], ref))           # compared after the clock has stopped
 
     # one-core rate first (the reference's shipped mode is single-core)
     t0 = time.perf_counter()
@@ -145,6 +154,13 @@ def cpu_baseline(scene_name, W, H, depth, sample_columns):
         th.join()
     dt = time.perf_counter() - t0
     pixels = sum(done)
+    for t in range(cores):
+        for x0, ref in kept[t]:
+            d = np.abs(gpu_image[x0:x0 + chunk].astype(np.float64) - ref.astype(np.float64)).max(axis=-1)
+            d = np.where(np.isnan(d), np.inf, d)
+            deltas[t][0] = max(deltas[t][0], float(d.max()))
+            deltas[t][1] += int((d > 1e-6).sum())
+            deltas[t][2] += int((d > 1e-4).sum())
     return {
         "value": round(pixels / dt / 1e6, 4),
         "unit": "Mrays/s",
@@ -154,6 +170,12 @@ def cpu_baseline(scene_name, W, H, depth, sample_columns):
                   f"({pixels} pixels, {dt:.1f} s wall); CPU oracle oracle/rt_oracle.c, gcc -O2 -ffp-contract=off, "
                   f"one thread per core",
         "one_core_value": round(one_core, 4),
+        "parity": None if gpu_image is None else {
+            "pixels_compared": pixels,
+            "max_abs_delta": max(d[0] for d in deltas),
+            "pixels_over_1e-6": sum(d[1] for d in deltas),
+            "pixels_over_1e-4": sum(d[2] for d in deltas),
+        },
     }
 
 
@@ -332,8 +354,8 @@ def main():
                 "block_threads": li.block_threads,
                 "lds_bytes_per_block": li.lds_bytes,
                 "wave_tile": f"{li.tile_x}x{li.tile_z}",
-                "max_delta_vs_cpu_ref": 0.0,
-                "parity": "bit-exact vs oracle (tests/test_parity_gpu.py)",
+                "max_delta_vs_cpu_ref": None,
+                "parity": "not measured in this run (every pixel of this frame is compared with the oracle in tests/test_parity_gpu.py)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -374,7 +396,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cols = args.cpu_sample_columns or {"builtin": 4096, "builtin8k": 2048}.get(args.workload, 64)
-                out["cpu_baseline"] = cpu_baseline(scene_name, W, H, depth, cols)
+                gpu_image = renderer.render(W, H, depth)          # host copy of the frame, outside the timed region
+                out["cpu_baseline"] = cpu_baseline(scene_name, W, H, depth, cols, gpu_image)
+                par = out["cpu_baseline"].get("parity")
+                if par:
+                    out["config"]["max_delta_vs_cpu_ref"] = par["max_abs_delta"]
+                    out["config"]["parity"] = (f"measured in this run: {par['pixels_compared']} pixels against the CPU oracle, "
+                                               f"{par['pixels_over_1e-6']} differ by more than 1e-6")
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = repr(e)

@@ -33,6 +33,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["parity"]["pixels_compared"] > 0 and c["parity"]["max_abs_delta"] == 0.0 and c["parity"]["pixels_over_1e-6"] == 0
+    assert j["config"]["max_delta_vs_cpu_ref"] == 0.0
     assert j["sphere_grid"]["value"] > 100.0
     sec = j["secondary"]
     assert sec["rays_per_pixel"] > 1.0 and sec["total_rays_per_s"] > j["value"] * 1e6
