@@ -48,7 +48,9 @@ enum { RT_KIND_SPHERE = 0, RT_KIND_INFINITE_PLANE = 1, RT_KIND_FINITE_PLANE = 2 
  * the derived geometry each primitive's constructor computes
  * (src/SceneSphere.cpp:44-48, src/SceneInfinitePlane.cpp:11-26,
  * src/SceneFinitePlane.cpp:18-80).  Objects are listed in Scene index order;
- * that order is observable (nearest-hit ties, per-light clamp order). */
+ * that order is observable (nearest-hit ties, per-light clamp order).  At most
+ * 4 096 objects per scene (RT_ERR_CAPACITY beyond; the reference's Scene holds
+ * 3 999, src/Scene.h:8). */
 typedef struct rt_object_desc {
     int32_t kind;                 /* RT_KIND_*                                 */
     int32_t is_light;             /* SceneObject::isaLightSource               */
@@ -173,6 +175,11 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *   "grid_mult"     persistent grid = occupancy x CUs x this; 0 = no persistence
  *   "first_row"     where the tile queues start, thousandths of the image
  *                   height (rows wrap around); -1 = automatic
+ *   "cull"          0 = the plain scans of the reference: every object one item in
+ *                   Scene index order, no wavefront-level culling, no
+ *                   nearest-first early exit, no sphere clustering, no
+ *                   axis-aligned route (the slow baseline the fast path is
+ *                   checked against, pixel for pixel, in tests/)
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
  *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */
 int rt_set_option(rt_scene *scene, const char *key, int value);

@@ -9,6 +9,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# torch first: it carries its own copy of the HIP runtime, and a process that has already
+# initialised the system one through libtcrt.so (DT_NEEDED /opt/rocm/lib/libamdhip64.so) finds
+# "No HIP GPUs" when torch initialises afterwards; the other order works (seen on the GPU box
+# when test_parity_gpu.py is collected alone).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is only plumbing for a few tests
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -80,6 +80,18 @@ def test_invalid_descriptions_are_rejected_before_touching_a_device():
     assert lib.rt_scene_destroy(None) == capi.RT_OK
 
 
+def test_more_objects_than_the_index_field_holds_is_a_capacity_error():
+    """The item tables carry a 12-bit Scene index: 4 096 objects (the reference's Scene stops at
+    3 999, src/Scene.h:8).  More is refused at create time, before any device is touched."""
+    host = HostScene.builtin()
+    d = _copy_desc(host.desc)
+    n = 4097
+    objs = (capi.RtObjectDesc * n)(*[d.objects[i % 32] for i in range(n)])
+    d.objects, d.n_objects, d.shadow_begin, d.shadow_end = objs, n, 0, n
+    rc, msg = _create(d)
+    assert rc == capi.RT_ERR_CAPACITY and "4096" in msg
+
+
 def test_no_gpu_means_no_render(have_gpu):
     if have_gpu:
         pytest.skip("a GPU is present")

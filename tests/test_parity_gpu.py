@@ -467,3 +467,167 @@ def test_counting_build_matches_and_counts(oracle):
     c = oracle.OracleScene.counters()
     assert st["nearest_rays"] == c.nearest_rays          # same rays traced as the reference restatement
     assert st["shadow_rays"] == c.shadow_rays
+
+
+# ------------------------------------------------ round 2: culls against the plain scan
+def _nested_spheres(scene, swap=False):
+    """The camera (setSceneTwoMirrors: eye (0,-1,2.5)) inside two nested spheres.  A ray that
+    starts inside a sphere reports root1 = v - sqrt(d^2) < 0 (src/SceneSphere.cpp:136-140), so
+    the OUTER sphere is the nearest hit whatever the Scene order; with >= 8 items and >= 4
+    candidates the nearest-first route of the kernel runs, and it must not stop after the first
+    sphere whose box contains the origins."""
+    i = scene.add_sphere((3.0, 5.0, 8.0), 0.15)
+    scene.set_light(i)
+    radii = (9.0, 4.0) if swap else (4.0, 9.0)
+    for k, r in enumerate(radii):
+        i = scene.add_sphere((0.25, -0.5, 2.0), r)
+        scene.set_color(i, [(1, 0, 0), (0, 0, 1)][k])
+        scene.set_reflective(i, 0.5)
+        scene.set_diffuse(i, 0.5)
+    for k in range(7):
+        i = scene.add_sphere((-3.0 + k, 1.5 + 0.25 * k, 2.0 + 0.1 * k), 0.4)
+        scene.set_color(i, (0, 1, 0))
+        if k % 2:
+            scene.set_reflective(i, 1.0)
+    i = scene.add_infinite_plane((0.0, 0.0, -1.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+    scene.set_reflective(i, 0.5)
+    i = scene.add_infinite_plane((0.0, 0.0, 6.0), (0.0, 0.0, -1.0), (1.0, 0.0, 0.0))
+    scene.set_specular(i, 0.5)
+    scene.set_object_indices(0, 1)
+    scene.camera_two_mirrors()
+    return scene
+
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_camera_inside_nested_spheres(oracle, swap):
+    host = _nested_spheres(HostScene.empty(), swap)
+    orc = _nested_spheres(oracle.OracleScene(), swap)
+    want = orc.render(72, 64, 5)
+    r = Renderer(host)
+    assert_same(r.render(72, 64, 5), want, f"nested spheres, swap={swap}")
+    r.set_option("cull", 0)
+    assert_same(r.render(72, 64, 5), want, f"nested spheres, plain scan, swap={swap}")
+
+
+def test_inside_a_clustered_sphere_field(oracle):
+    """Negative-distance hits inside a clustered run: overlapping big spheres around the camera."""
+    def build(scene):
+        rng = np.random.RandomState(7)
+        i = scene.add_sphere((3.0, 5.0, 8.0), 0.15)
+        scene.set_light(i)
+        for k in range(80):
+            big = k % 9 == 0
+            c = (float(np.float32(rng.uniform(-2, 2))), float(np.float32(rng.uniform(-2, 6))), float(np.float32(rng.uniform(1, 4))))
+            i = scene.add_sphere(c, float(np.float32(rng.uniform(6, 12) if big else rng.uniform(0.2, 0.8))))
+            scene.set_color(i, [(1, 0, 0), (0, 1, 0), (0, 0, 1)][k % 3])
+            if k % 2:
+                scene.set_reflective(i, 0.5)
+        scene.add_infinite_plane((0.0, 0.0, -1.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+        scene.set_object_indices(0, 1)
+        scene.camera_two_mirrors()
+        return scene
+    want = build(oracle.OracleScene()).render(64, 64, 4)
+    r = Renderer(build(HostScene.empty()))
+    assert_same(r.render(64, 64, 4), want, "inside a clustered field")
+    r.set_option("cull", 0)
+    assert_same(r.render(64, 64, 4), want, "inside a clustered field, plain scan")
+
+
+@pytest.mark.parametrize("name,W,H,depth", [("builtin", 150, 130, 4), ("grid16", 96, 96, 8), ("grid32", 64, 96, 4)])
+def test_plain_scan_option(oracle, name, W, H, depth):
+    """rt_set_option("cull", 0): no bundle culls, no nearest-first exit, no sphere clustering, no
+    axis-aligned route -- the in-order scans of src/RayTracer.cpp:50-89, 709-739 as they stand."""
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    r.set_option("cull", 0)
+    assert_same(r.render(W, H, depth), want, f"{name}, cull 0")
+    r.set_option("cull", 1)
+    assert_same(r.render(W, H, depth), want, f"{name}, cull 1 again")
+
+
+def _frames_equal_on_device(a, b):
+    import torch
+    return bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+
+
+@pytest.mark.parametrize("name,depth,cols", [
+    ("grid32", 4, [3, 2047, 2048, 4001]),            # configs[2]
+    ("grid16", 8, [9, 1531, 2050, 3777]),            # configs[4]
+])
+def test_4096_sphere_grid_every_pixel_culls_vs_plain_scan(oracle, name, depth, cols):
+    """Full 4096 x 4096 frames of the sphere-grid configs: the default kernel (bundle culls,
+    nearest-first exit, clustered runs) against the plain in-order scan on EVERY pixel, and the
+    plain frame against the oracle on whole columns (horizon rows included)."""
+    import torch
+    W = H = 4096
+    r = Renderer(HostScene.named(name))
+    stream = torch.cuda.current_stream().cuda_stream
+    fast = torch.empty((W, H, 3), dtype=torch.float32, device="cuda:0")
+    plain = torch.empty((W, H, 3), dtype=torch.float32, device="cuda:0")
+    r.render_device(W, H, depth, 0, W, fast.data_ptr(), stream)
+    r.set_option("cull", 0)
+    r.render_device(W, H, depth, 0, W, plain.data_ptr(), stream)
+    torch.cuda.synchronize()
+    if not _frames_equal_on_device(fast, plain):
+        bad = (fast.view(torch.int32) != plain.view(torch.int32)).any(dim=-1).nonzero()
+        raise AssertionError(f"{name}: {len(bad)} pixels differ between the default kernel and the plain scan, first {bad[0].tolist()}")
+    for x0, want in _oracle_columns(oracle, lambda: oracle.OracleScene.named(name), W, H, depth, cols).items():
+        assert_same(plain[x0:x0 + 1].cpu().numpy(), want, f"{name} plain scan, column {x0}")
+
+
+def test_8192_builtin_as_eight_strips(oracle):
+    """configs[3]: the 8192 x 8192 frame as eight 1024-column x-strips, the per-rank calls of the
+    static partition (src/RayTracer.cpp:904-923 with CORE_NUM = 8) through rt_render_device."""
+    import torch
+    W = H = 8192
+    depth = 4
+    r = Renderer(HostScene.builtin())
+    stream = torch.cuda.current_stream().cuda_stream
+    full = torch.empty((W, H, 3), dtype=torch.float32, device="cuda:0")
+    r.render_device(W, H, depth, 0, W, full.data_ptr(), stream)
+    strip = torch.empty((1024, H, 3), dtype=torch.float32, device="cuda:0")
+    for g in range(8):
+        strip.fill_(-1.0)
+        r.render_device(W, H, depth, g * 1024, (g + 1) * 1024, strip.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert _frames_equal_on_device(strip, full[g * 1024:(g + 1) * 1024]), f"strip {g} differs from the full render"
+    want = np.fromfile(os.path.join(GOLDEN, "b64d4.f32"), dtype=np.float32).reshape(64, 64, 3)
+    assert_same(full[::128, ::128].contiguous().cpu().numpy(), want, "stride-128 subsample")   # (float)(128k)/8192 == (float)k/64
+    cols = [1, 513, 1023, 1025, 2047, 2049, 3071, 3073, 4095, 4097, 5119, 5121, 6143, 6145, 7167, 7169, 8191]
+    for x0, got in _oracle_columns(oracle, lambda: oracle.OracleScene.builtin(), W, H, depth, cols).items():
+        assert_same(full[x0:x0 + 1].cpu().numpy(), got, f"column {x0}")
+
+
+@pytest.mark.parametrize("first", [5000, 5025, 5050, 5075])
+def test_fuzz_slice(oracle, first):
+    """A bounded slice (100 seeds in all) of scripts/fuzz_gpu.py's randomised sweep."""
+    from scene_gen import build_random, build_sphere_field
+    for seed in range(first, first + 25):
+        rng = np.random.RandomState(seed)
+        if seed % 4 == 0:
+            n = int(rng.choice([64, 80, 130, 260]))
+            spread = float(rng.choice([30.0, 60.0, 200.0]))
+            mk = lambda s: build_sphere_field(s, seed, n_spheres=n, spread=spread)
+            W, H, depth = 40, int(rng.choice([64, 512, 2048])), int(rng.randint(1, 6))
+        else:
+            kw = dict(n_spheres=int(rng.randint(0, 40)), n_finite=int(rng.randint(0, 12)), n_infinite=int(rng.randint(0, 3)),
+                      n_lights=int(rng.randint(1, 4)), shadows=bool(rng.rand() < 0.8))
+            mk = lambda s: build_random(s, seed, **kw)
+            W, H, depth = int(rng.randint(1, 90)), int(rng.randint(1, 90)), int(rng.randint(0, 9))
+        r = Renderer(mk(HostScene.empty()))
+        if seed % 3 == 0:
+            r.set_option("tile_z", int(2 ** rng.randint(0, 7)))
+        assert_same(r.render(W, H, depth), mk(oracle.OracleScene()).render(W, H, depth), f"fuzz seed {seed}")
+
+
+def test_failed_option_leaves_the_handle_usable(oracle):
+    """An option the scene cannot be re-packed with is refused and changes nothing."""
+    from tilecoderaytracer_amd import RtError
+    want = oracle.OracleScene.two_mirrors().render(24, 24, 3)
+    r = Renderer(HostScene.two_mirrors())
+    for key, value in (("cluster_leaf", 0), ("leaf_items", 0), ("cluster_group", 1), ("cull", 0)):
+        try:
+            r.set_option(key, value)
+        except RtError:
+            pass
+        assert_same(r.render(24, 24, 3), want, f"after {key}={value}")

@@ -81,6 +81,7 @@ struct rt_scene {
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
+    int cull_opt = 1;             /* 0: plain in-order scans -- no bundle cull, no nearest-first exit, no clustering, no AA route */
     int n_clusters = 0;
     /* tile queue heads, one per in-flight launch (same ring as the events) */
     unsigned int *d_counters = nullptr;
@@ -184,6 +185,9 @@ int pack_scene(rt_scene *s) {
     const int n = (int)s->objects.size();
     const rt_object_desc *objs = s->objects.data();
     const int sb = s->shadow_begin, se = s->shadow_end;
+    /* option "cull" = 0: every object is a plain item in Scene index order */
+    const int cluster_leaf = s->cull_opt ? s->cluster_leaf : 0;
+    const bool aa_planes = s->cull_opt && s->aa_planes;
 
     std::vector<Quad> geom, lights, mats, texs, clusters;
     std::vector<uint32_t> objinfo((size_t)n, 0u), cidx;
@@ -246,7 +250,7 @@ int pack_scene(rt_scene *s) {
         }
     };
 
-    s->n_clusters = 0;
+    int n_clusters = 0;
     /* Cluster/idx offsets are patched once the section bases are known. */
     std::vector<int> aa_all;                         /* axis-aligned finite planes (Scene indices) */
     std::vector<int> aa_rec_of((size_t)n, -1);       /* their AA test record (quad offset within aa_recs) */
@@ -265,7 +269,7 @@ int pack_scene(rt_scene *s) {
         const int s0 = std::max(first, sb), s1 = std::min(last, se);
         const bool in_shadow_all = !sp.light && s0 == first && s1 == last;
         const bool in_shadow_none = sp.light || s0 >= s1;
-        bool cluster = sp.kind == RT_KIND_SPHERE && s->cluster_leaf > 0 && sp.count >= 4 * s->cluster_leaf &&
+        bool cluster = sp.kind == RT_KIND_SPHERE && cluster_leaf > 0 && sp.count >= 4 * cluster_leaf &&
                        (in_shadow_all || in_shadow_none);
         if (cluster)
             for (int i = first; i < last; ++i) cluster = cluster && all_finite(objs[i]);
@@ -273,7 +277,7 @@ int pack_scene(rt_scene *s) {
             std::vector<int> ids((size_t)sp.count);
             for (int i = 0; i < sp.count; ++i) ids[(size_t)i] = first + i;
             std::vector<Leaf> leaves;
-            split_leaves(objs, ids, s->cluster_leaf, leaves);
+            split_leaves(objs, ids, cluster_leaf, leaves);
             /* leaves come out of the k-d split in spatial order: every `group`
              * consecutive leaves form a group with its own bounding ball */
             const int G = std::max(1, s->cluster_group);
@@ -311,8 +315,8 @@ int pack_scene(rt_scene *s) {
                     leaf_items.push_back(li);
                 }
             }
-            s->n_clusters += (int)leaves.size();
-        } else if (sp.kind == RT_KIND_FINITE_PLANE && s->aa_planes) {
+            n_clusters += (int)leaves.size();
+        } else if (sp.kind == RT_KIND_FINITE_PLANE && aa_planes) {
             /* axis-aligned members leave the in-order run for the class-sorted tables built below */
             for (int i = first; i < last; ++i) emit_geometry(i);
             int i = first;
@@ -351,19 +355,19 @@ int pack_scene(rt_scene *s) {
         objinfo[(size_t)i] = (uint32_t)geom_off[(size_t)i] | ((uint32_t)objs[i].kind << 16) |
                              ((uint32_t)mat_of[(size_t)i] << 20);
 
-    /* assemble the image */
-    RtParams &b = s->base;
+    /* assemble the image (into temporaries: a failure below leaves the handle as it was) */
+    RtParams b;
     std::memset(&b, 0, sizeof(b));
-    s->image.clear();
-    s->image.insert(s->image.end(), geom.begin(), geom.end());
-    const int clusters_off = (int)s->image.size();
-    s->image.insert(s->image.end(), clusters.begin(), clusters.end());
-    const int aa_off = (int)s->image.size();
-    s->image.insert(s->image.end(), aa_recs.begin(), aa_recs.end());
+    std::vector<Quad> image;
+    image.insert(image.end(), geom.begin(), geom.end());
+    const int clusters_off = (int)image.size();
+    image.insert(image.end(), clusters.begin(), clusters.end());
+    const int aa_off = (int)image.size();
+    image.insert(image.end(), aa_recs.begin(), aa_recs.end());
     /* Scene-index tables of the clustered / class-sorted runs */
-    const int cidx_off = (int)s->image.size();
-    s->image.resize(s->image.size() + (cidx.size() + 3) / 4, Quad{{0, 0, 0, 0}});
-    if (!cidx.empty()) std::memcpy(s->image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
+    const int cidx_off = (int)image.size();
+    image.resize(image.size() + (cidx.size() + 3) / 4, Quad{{0, 0, 0, 0}});
+    if (!cidx.empty()) std::memcpy(image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
 
     /* Item tables (rt_tables.h): one item per object that is not part of a clustered run, in
      * Scene order, then one per leaf (or group) of each clustered run.  `near_items` covers every object,
@@ -473,28 +477,31 @@ int pack_scene(rt_scene *s) {
                 if (g.in_shadow) group_item(shadow_items, g);
         }
     }
-    b.near_items_off = (int)s->image.size();
+    b.near_items_off = (int)image.size();
     b.n_near_items = (int)(near_items.size() / 2);
-    s->image.insert(s->image.end(), near_items.begin(), near_items.end());
-    b.shadow_items_off = (int)s->image.size();
+    image.insert(image.end(), near_items.begin(), near_items.end());
+    b.shadow_items_off = (int)image.size();
     b.n_shadow_items = (int)(shadow_items.size() / 2);
-    s->image.insert(s->image.end(), shadow_items.begin(), shadow_items.end());
-    b.lights_off = (int)s->image.size();
-    s->image.insert(s->image.end(), lights.begin(), lights.end());
-    b.mat_off = (int)s->image.size();
-    s->image.insert(s->image.end(), mats.begin(), mats.end());
-    b.tex_off = (int)s->image.size();
-    s->image.insert(s->image.end(), texs.begin(), texs.end());
-    b.objinfo_off = (int)s->image.size();
-    s->image.resize(s->image.size() + ((size_t)n + 3) / 4, Quad{{0, 0, 0, 0}});
-    if (n > 0) std::memcpy(s->image[(size_t)b.objinfo_off].v, objinfo.data(), (size_t)n * 4);
-    if (s->image.empty()) s->image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
-    b.image_quads = (int)s->image.size();
-    b.n_clusters = s->n_clusters;
+    image.insert(image.end(), shadow_items.begin(), shadow_items.end());
+    b.lights_off = (int)image.size();
+    image.insert(image.end(), lights.begin(), lights.end());
+    b.mat_off = (int)image.size();
+    image.insert(image.end(), mats.begin(), mats.end());
+    b.tex_off = (int)image.size();
+    image.insert(image.end(), texs.begin(), texs.end());
+    b.objinfo_off = (int)image.size();
+    image.resize(image.size() + ((size_t)n + 3) / 4, Quad{{0, 0, 0, 0}});
+    if (n > 0) std::memcpy(image[(size_t)b.objinfo_off].v, objinfo.data(), (size_t)n * 4);
+    if (image.empty()) image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
+    b.image_quads = (int)image.size();
+    b.n_clusters = n_clusters;
     b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
     for (int c = 0; c < 3; ++c) b.null_color[c] = s->null_color[c];
     if ((size_t)b.image_quads * 16 > RT_MAX_LDS_BYTES)
         return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
+    s->image.swap(image);
+    s->base = b;
+    s->n_clusters = n_clusters;
     return RT_OK;
 }
 
@@ -503,6 +510,8 @@ int adopt_desc(const rt_scene_desc *desc, rt_scene *s) {
     const int n = desc->n_objects;
     if (n < 0) return fail(RT_ERR_INVALID, "n_objects < 0");
     if (n > 0 && !desc->objects) return fail(RT_ERR_INVALID, "objects is NULL");
+    if (n > RT_MAX_OBJECTS)
+        return fail(RT_ERR_CAPACITY, "more than " + std::to_string(RT_MAX_OBJECTS) + " objects (the reference's Scene holds 3 999, src/Scene.h:8)");
     if (desc->n_textures < 0 || (desc->n_textures > 0 && !desc->textures))
         return fail(RT_ERR_INVALID, "bad textures");
     if (desc->shadow_begin < 0 || desc->shadow_end < desc->shadow_begin || desc->shadow_end > n)
@@ -651,6 +660,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.shw = cam->screen_halfwidth; p.shh = cam->screen_halfheight;
     p.W = W; p.H = H; p.x0 = x0; p.x1 = x1; p.max_depth = max_depth;
     p.stack_lds_levels = stack_lds_levels;
+    p.cull = s->cull_opt;
     /* Wavefront tile shape (speed only).  4 x 16 (x by z) makes every lane-row's
      * stores whole 64-byte sectors (16 pixels x 12 B = 192 B, aligned): measured
      * WRITE_SIZE = 1.08 x the framebuffer bytes vs 1.27 x for 16 x 4.  On the
@@ -949,32 +959,30 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         s->grid_mult = value;
         return RT_OK;
     }
-    if (!std::strcmp(key, "leaf_items")) {
-        const int old = s->leaf_items_opt;
-        s->leaf_items_opt = value != 0;
+    /* options that change the tables: pack_scene() commits only on success, so a value the
+     * scene cannot be packed with leaves the handle exactly as it was */
+    auto repack_with = [&](int &field, int v) {
+        const int old = field;
+        if (old == v) return (int)RT_OK;
+        field = v;
         int rc = pack_scene(s);
-        if (rc == RT_OK) rc = upload_scene(s);
-        if (rc) { s->leaf_items_opt = old; return rc; }
-        return RT_OK;
-    }
-    if (!std::strcmp(key, "aa_planes")) {
-        const int old = s->aa_planes;
-        s->aa_planes = value != 0;
-        int rc = pack_scene(s);
-        if (rc == RT_OK) rc = upload_scene(s);
-        if (rc) { s->aa_planes = old; return rc; }
-        return RT_OK;
-    }
+        if (rc) { field = old; return rc; }
+        rc = upload_scene(s);
+        if (rc) {                                   /* device trouble: go back to the tables that were there */
+            const std::string why = g_last_error;
+            field = old;
+            if (pack_scene(s) == RT_OK) (void)upload_scene(s);
+            return fail(rc, why);
+        }
+        return (int)RT_OK;
+    };
+    if (!std::strcmp(key, "leaf_items")) return repack_with(s->leaf_items_opt, value != 0);
+    if (!std::strcmp(key, "aa_planes")) return repack_with(s->aa_planes, value != 0);
+    if (!std::strcmp(key, "cull")) return repack_with(s->cull_opt, value != 0);
     if (!std::strcmp(key, "cluster_leaf") || !std::strcmp(key, "cluster_group")) {
         const bool leaf = !std::strcmp(key, "cluster_leaf");
         if (value < (leaf ? 0 : 1) || value > 255) return fail(RT_ERR_INVALID, "cluster_leaf in [0,255], cluster_group in [1,255]");
-        int &field = leaf ? s->cluster_leaf : s->cluster_group;
-        const int old = field;
-        field = value;
-        int rc = pack_scene(s);
-        if (rc == RT_OK) rc = upload_scene(s);
-        if (rc) { field = old; return rc; }
-        return RT_OK;
+        return repack_with(leaf ? s->cluster_leaf : s->cluster_group, value);
     }
     return fail(RT_ERR_INVALID, std::string("unknown option: ") + key);
 }

@@ -454,7 +454,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
 
     /* the bundle (a handful of items is not worth bounding it for) */
     float dminx = -inf, dmaxx = inf, dminy = -inf, dmaxy = inf, dminz = -inf, dmaxz = inf;
-    bool cull = p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
+    bool cull = p.cull != 0 && p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
     if (cull) {
 #ifdef RT_OLD_REDUCTIONS
         dminx = wave_min(active ? d.x : inf); dmaxx = wave_max(active ? d.x : -inf);
@@ -557,7 +557,10 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 if (nearest_key == 0xFFFFFFFFu) break;                 /* cannot happen while mask != 0; keeps the loop finite regardless */
                 src = (int)(nearest_key & 63u);
                 const float entry = __uint_as_float(nearest_key & ~63u);
-                if (!wave_any(active && !(entry - 1.0e-4f * entry - 1.0e-6f > best))) break;
+                /* entry == 0: the origin box meets the item's box, and a ray that starts inside a
+                 * sphere reports a NEGATIVE distance (root1, src/SceneSphere.cpp:136-140): such
+                 * items are always tested, whatever the lanes hold already */
+                if (entry > 0.0f && !wave_any(active && !(entry - 1.0e-4f * entry - 1.0e-6f > best))) break;
                 if (lane == src) key = 0xFFFFFFFFu;
                 mask &= ~(1ull << src);
             } else {
@@ -676,7 +679,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
      * the point at parameter s of any of them is within (1-s) e of c + s (light - c).
      * An item can matter only if its box, grown by e (and the rounding slack),
      * meets that centre segment for some s in [0, 1]: a slab test per item-lane. */
-    const bool cull = p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS;
+    const bool cull = p.cull != 0 && p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS;
     const V3 c = origins_centre;             /* both from shading_point_bundle(), once per bounce level */
     V3 e = origins_half, sinv = mk(0, 0, 0); /* e: half-extent, plus slack below */
     if (cull) {
@@ -1007,7 +1010,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         if (shade) C = mk(0.0f, 0.0f, 0.0f);
         if (wave_any(shade)) {
             /* box of the shading points, shared by every light's shadow scan */
-            have_box = p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
+            have_box = p.cull != 0 && (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS);
             if (have_box) {
 #ifdef RT_OLD_REDUCTIONS
                 const float inf = __builtin_huge_valf();
@@ -1018,7 +1021,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 #endif
             }
             V3 bundle_centre = mk(0, 0, 0), bundle_half = bundle_centre;
-            if (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
+            if (p.cull != 0 && p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];

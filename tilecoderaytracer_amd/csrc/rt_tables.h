@@ -90,6 +90,7 @@
 
 #define RT_MAX_GEOM_QUADS 65535   /* 16-bit geometry offset in objinfo */
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
+#define RT_MAX_OBJECTS    4096    /* 12-bit Scene index in the item tables */
 #define RT_MAX_LDS_BYTES  (160 * 1024)
 #ifndef RT_STACK_LDS_SHARE
 #define RT_STACK_LDS_SHARE 7      /* tables + the LDS part of the bounce stack must fit this many times per CU */
@@ -135,6 +136,7 @@ typedef struct RtParams {
     int32_t n_tiles;                     /* total wavefront tiles   */
     int32_t stack_lds_levels;            /* bounce levels below this keep their stack entries in LDS (behind the tables), the others in HBM */
     int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around */
+    int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
 } RtParams;
 
 #endif /* RT_TABLES_H_ */
