@@ -46,7 +46,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -65,6 +64,42 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PIXEL = 12             # 3 x fp32 framebuffer store, SURVEY.md section 8(d)
+CLOCK_HZ = 2.4e9                 # MI355X_MICROARCH.md: 2.4 GHz peak engine clock
+N_SIMDS = 256 * 4                # 256 CUs x 4 SIMD-32
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * CLOCK_HZ     # one non-fused fp32 op per SIMD lane and clock (157.3 TF counts FMA = 2)
+KERNEL_SOURCES = ("rt_kernel.hip", "rt_capi.hip", "rt_tables.h")
+
+
+def kernel_source_digest():
+    """SHA-256 over the kernel's source files: ties a counter profile to the build it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "tilecoderaytracer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def valu_issue_roofline(rec, kernel_ms):
+    """The binding roofline of this kernel: vector-instruction issue.  A wave64 fp32 instruction
+    occupies its SIMD-32 for 2 cycles by the guide (2.5 measured for dependent non-fused ops,
+    scripts/ubench/valu_rate.hip), so SQ_INSTS_VALU / 1 024 SIMDs x that = the cycles the VALU
+    pipes were busy; against the kernel's cycles (duration x 2.4 GHz)."""
+    insts = float(rec["sq_insts_valu"])
+    kernel_cycles = kernel_ms * 1e-3 * CLOCK_HZ
+    at2 = insts / N_SIMDS * 2.0
+    at25 = insts / N_SIMDS * 2.5
+    return {
+        "bound": "valu_issue",
+        "sq_insts_valu_per_launch": insts,
+        "sq_insts_salu_per_launch": rec.get("sq_insts_salu"),
+        "sq_busy_cycles_per_engine": rec.get("sq_busy_cycles_per_engine"),
+        "kernel_cycles_at_2.4GHz": round(kernel_cycles, 0),
+        "valu_issue_cycles_per_simd_at_2": round(at2, 0),
+        "frac_at_2_cycles_per_wave64_op": round(at2 / kernel_cycles, 4) if kernel_cycles > 0 else None,
+        "frac_at_2.5_cycles_measured": round(at25 / kernel_cycles, 4) if kernel_cycles > 0 else None,
+        "source": "SQ_INSTS_VALU from profiles/pmc_traffic.json (profiles/*_pmc_sq.csv), kernel time from this run's HIP events",
+    }
 
 
 def parse_args():
@@ -90,92 +125,136 @@ def parse_args():
                          "warm-up steps (rank 0, which receives, renders more when a link is slower than a GPU); "
                          "'equal' keeps N equal strips")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: gather each frame before rendering the next (no render/gather pipelining)")
+                    help="(accepted for compatibility; the headline at N > 1 is always the single-frame figure)")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="N > 1: skip the second, pipelined measurement (gather of frame k under the render of frame k+1)")
     return ap.parse_args()
 
 
-def usable_cores():
-    """Host cores this process may really use: the affinity mask, capped by the
-    cgroup CPU quota (a container can see 256 CPUs and be allowed 16)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def host_cores():
+    """(cpus, note): one logical CPU per PHYSICAL core this process may use -- the affinity
+    mask, one SMT sibling per (package, core) of /proc/cpuinfo -- capped by the cgroup CPU
+    quota (a container can see 256 CPUs and be allowed 16).  The CPU leg pins one thread to each."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    core_of = {}
+    try:
+        cpu = None
+        phys = core = 0
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu, phys, core = int(v), 0, None
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id":
+                core = int(v)
+            elif not k and cpu is not None:
+                core_of[cpu] = (phys, core if core is not None else cpu)
+                cpu = None
+    except Exception:
+        core_of = {}
+    seen, cpus = set(), []
+    for c in allowed:
+        key = core_of.get(c, ("?", c))
+        if key not in seen:
+            seen.add(key)
+            cpus.append(c)
+    physical = len(cpus)
+    quota = None
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
             if path.endswith("cpu.max"):
                 if txt[0] != "max":
-                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+                    quota = max(1, int(float(txt[0]) / float(txt[1])))
             else:
-                quota = int(txt[0])
+                q = int(txt[0])
                 period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if quota > 0:
-                    n = min(n, max(1, quota // period))
+                if q > 0:
+                    quota = max(1, q // period)
             break
         except Exception:
             continue
-    return max(1, min(n, 64))
+    n = min(physical, quota or physical, 64)
+    if n < physical:
+        # fewer threads than cores (a quota inside a big machine shared with other jobs): leave the
+        # placement to the scheduler, which avoids busy cores; pinning could land on one
+        pin = False
+        cpus = cpus[:n]
+    else:
+        pin = True
+    note = (f"{len(allowed)} logical CPUs in the affinity mask = {physical} physical cores"
+            + (f", cgroup quota {quota}" if quota else "") + f"; {len(cpus)} threads"
+            + (", one pinned per physical core" if pin else ", placed by the scheduler"))
+    if not pin:
+        cpus = [-1] * len(cpus)
+    return cpus, note
 
 
-def cpu_baseline(scene_name, W, H, depth, sample_columns, gpu_image=None):
-    """Time the CPU oracle on all host cores over evenly spread column chunks; with
-    gpu_image (the GPU's W x H x 3 frame on the host) also compare every sampled
-    column with it -- the "max per-channel delta vs CPU ref" half of the metric."""
+def cpu_baseline(scene_name, W, H, depth, sample_columns, gpu_image=None, repeats=3):
+    """Time the CPU oracle on the host: one core (the reference's shipped mode,
+    PARTIONING_STRATEGY 0) and all physical cores with the reference's static partitioning
+    (strategy 1, src/RayTracer.cpp:904-923 with CORE_NUM > 1: contiguous shares, C threads inside
+    the oracle harness, oracle/rt_oracle_mt.c), median of `repeats` runs.  With gpu_image (the
+    GPU's W x H x 3 frame on the host) every sampled column is also compared with it -- the
+    "max per-channel delta vs CPU ref" half of the metric -- after the clocks have stopped."""
+    import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib  # noqa: E402  (the oracle is the thing timed here, nothing else uses it)
 
-    cores = usable_cores()
+    cpus, core_note = host_cores()
+    cores = len(cpus)
     chunk = 8
-    n_chunks = max(cores, sample_columns // chunk)
-    n_chunks = min(n_chunks, W // chunk)
-    starts = [int(i * (W - chunk) / max(n_chunks - 1, 1)) for i in range(n_chunks)]
-    scenes = [oracle_lib.OracleScene.named(scene_name) for _ in range(cores)]
-    done = [0] * cores
+    n_chunks = min(max(cores, sample_columns // chunk), W // chunk)
+    starts = [int(i * (W - chunk) / max(n_chunks - 1, 1)) for i in range(n_chunks)]      # ascending, evenly spread
+    scene = oracle_lib.OracleScene.named(scene_name)
+    out = np.empty((n_chunks * chunk, H, 3), dtype=np.float32)
+    c_starts = (C.c_int * n_chunks)(*starts)
+    c_cpus = (C.c_int * cores)(*cpus)
+    pixels = n_chunks * chunk * H
 
-    deltas = [[0.0, 0, 0] for _ in range(cores)]       # per thread: max |d|, pixels > 1e-6, pixels > 1e-4
-    kept = [[] for _ in range(cores)]
+    def run(threads):
+        sec = C.c_double()
+        rc = oracle_lib.LIB.orc_render_static_partition(scene.h, C.byref(scene.cam), W, H, depth, c_starts, n_chunks, chunk,
+                                                        threads, c_cpus, out.ctypes.data, C.byref(sec))
+        if rc:
+            raise RuntimeError("orc_render_static_partition failed")
+        return sec.value
 
-    def work(t):
-        s = scenes[t]
-        for k in range(t, n_chunks, cores):
-            ref = s.render(W, H, depth, starts[k], starts[k] + chunk)
-            done[t] += chunk * H
-            if gpu_image is not None:
-                kept[t].append((starts[k], ref))           # compared after the clock has stopped
-
-    # one-core rate first (the reference's shipped mode is single-core)
-    t0 = time.perf_counter()
-    scenes[0].render(W, H, depth, starts[0], starts[0] + chunk)
-    one_core = chunk * H / (time.perf_counter() - t0) / 1e6
-
-    threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-    t0 = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    dt = time.perf_counter() - t0
-    pixels = sum(done)
-    for t in range(cores):
-        for x0, ref in kept[t]:
-            d = np.abs(gpu_image[x0:x0 + chunk].astype(np.float64) - ref.astype(np.float64)).max(axis=-1)
+    # one core: a sixteenth of the sample is enough for a steady figure
+    one_chunks = max(1, n_chunks // 16)
+    one_starts = (C.c_int * one_chunks)(*starts[:: max(1, n_chunks // one_chunks)][:one_chunks])
+    one_times = []
+    for _ in range(repeats):
+        sec = C.c_double()
+        oracle_lib.LIB.orc_render_static_partition(scene.h, C.byref(scene.cam), W, H, depth, one_starts, one_chunks, chunk, 1,
+                                                   c_cpus, out.ctypes.data, C.byref(sec))
+        one_times.append(sec.value)
+    one_core = one_chunks * chunk * H / float(np.median(one_times)) / 1e6
+    times = [run(cores) for _ in range(repeats)]
+    dt = float(np.median(times))
+    parity = None
+    if gpu_image is not None:
+        worst, over6, over4 = 0.0, 0, 0
+        for k, x0 in enumerate(starts):
+            d = np.abs(gpu_image[x0:x0 + chunk].astype(np.float64) - out[k * chunk:(k + 1) * chunk].astype(np.float64)).max(axis=-1)
             d = np.where(np.isnan(d), np.inf, d)
-            deltas[t][0] = max(deltas[t][0], float(d.max()))
-            deltas[t][1] += int((d > 1e-6).sum())
-            deltas[t][2] += int((d > 1e-4).sum())
+            worst = max(worst, float(d.max()))
+            over6 += int((d > 1e-6).sum())
+            over4 += int((d > 1e-4).sum())
+        parity = {"pixels_compared": pixels, "max_abs_delta": worst, "pixels_over_1e-6": over6, "pixels_over_1e-4": over4}
     return {
         "value": round(pixels / dt / 1e6, 4),
         "unit": "Mrays/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n_chunks} chunks of {chunk} columns x {H} rows spread over the {W}x{H} image "
-                  f"({pixels} pixels, {dt:.1f} s wall); CPU oracle oracle/rt_oracle.c, gcc -O2 -ffp-contract=off, "
-                  f"one thread per core",
+        "sample": f"{n_chunks} chunks of {chunk} columns x {H} rows spread over the {W}x{H} image ({pixels} pixels), "
+                  f"dealt to the threads in contiguous shares (the reference's static partitioning); median of {repeats} runs, "
+                  f"{dt:.2f} s wall each (all: {[round(t, 2) for t in times]}); CPU oracle oracle/rt_oracle.c, gcc -O2 -ffp-contract=off; "
+                  + core_note,
         "one_core_value": round(one_core, 4),
-        "parity": None if gpu_image is None else {
-            "pixels_compared": pixels,
-            "max_abs_delta": max(d[0] for d in deltas),
-            "pixels_over_1e-6": sum(d[1] for d in deltas),
-            "pixels_over_1e-4": sum(d[2] for d in deltas),
-        },
+        "parity": parity,
     }
 
 
@@ -218,9 +297,11 @@ def main():
 
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def measure(workload, steps, warmup, size=0):
+    def measure(workload, steps, warmup, size=0, overlap=False):
         """Warm up, then time exactly `steps` steps of `workload` between two fences
-        (barrier + synchronize); returns the MAX over ranks."""
+        (barrier + synchronize); returns the MAX over ranks.  overlap=False: every frame is
+        rendered and then gathered (one frame's latency); overlap=True: the
+        gather of frame k runs under the render of frame k+1 (throughput of a stream of frames)."""
         scene_name, W, H, depth, cfg_note = WORKLOADS[workload]
         if size:
             W = H = size
@@ -234,7 +315,7 @@ def main():
             k, v = kv.split("=")
             renderer.set_option(k, int(v))
         def make_pipe(bounds=None):
-            pp = StripPipeline(W, H, world, rank, dev, render=None, overlap=not args.no_overlap,
+            pp = StripPipeline(W, H, world, rank, dev, render=None, overlap=overlap,
                                force_gather=args.force_dist, bounds=bounds)
             a, b = pp.x0, pp.x1
             pp.render = lambda buf: renderer.render_device(W, H, depth, a, b, buf.data_ptr(), stream)
@@ -263,7 +344,7 @@ def main():
             my_kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
             bounds = None
             try:
-                bounds, partition_note = measure_and_balance(pipe, W, my_kernel_ms, fence, dev)
+                bounds, partition_note = measure_and_balance(pipe, W, my_kernel_ms, fence, dev, overlap=overlap)
             except Exception as e:                                         # never lose the run to the tuning step
                 partition_note = f"balanced partition unavailable ({e!r}); equal strips"
             # all ranks take the new strips, or none does
@@ -316,18 +397,47 @@ def main():
             "ms_per_step": round(g["elapsed"] / g_steps * 1e3, 4),
             "kernel_ms": round(g["kernel_ms"], 4),
             "partition": g["partition"],
+            "mode": "single frame: render, then gather" if world > 1 else "one launch per frame",
+        }
+    # N > 1: the throughput of a STREAM of frames (gather of frame k under the render of frame k+1),
+    # next to the single-frame headline; a different figure, labelled as such
+    pipelined = None
+    if world > 1 and not args.no_pipelined:
+        pm = measure(args.workload, args.steps, max(args.warmup, 3), args.size, overlap=True)
+        pipelined = {
+            "what": "stream of independent frames: RCCL gather of frame k overlapped with the render of frame k+1 "
+                    "(two strip buffers); NOT the single-frame figure `value` reports",
+            "value": round(pm["W"] * pm["H"] * args.steps / pm["elapsed"] / 1e6, 3),
+            "unit": "Mrays/s",
+            "ms_per_step": round(pm["elapsed"] / args.steps * 1e3, 4),
+            "partition": pm["partition"],
+            "partition_note": pm["partition_note"],
         }
 
     if rank == 0:
         li = renderer.launch_info()
         pixels_per_launch = (x1 - x0) * H
         achieved = BYTES_PER_PIXEL * pixels_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source, compute = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and world == 1 and not args.size:
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+                    prof = json.load(f)
+                rec = prof.get(args.workload, {})
+                same = prof.get("kernel_source_sha256") == kernel_source_digest()
+                traffic_source = {
+                    "file": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this bench command, scripts/profile_all.sh)",
+                    "profiled_kernel_source_sha256": prof.get("kernel_source_sha256"),
+                    "this_build_kernel_source_sha256": kernel_source_digest(),
+                    "same_kernel_source": same,
+                }
+                if same:
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    if rec.get("sq_insts_valu"):
+                        compute = valu_issue_roofline(rec, kernel_ms)
+                else:
+                    traffic_source["stale_hbm_bytes_per_launch"] = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -348,8 +458,7 @@ def main():
                 "baseline_config": cfg_note,
                 "objects": host.object_count,
                 "partition": m["partition"] + (
-                    ", RCCL gather to rank 0" + ("" if args.no_overlap else ", gather of frame k overlapped with render of frame k+1")
-                    if world > 1 else ""),
+                    ", RCCL gather to rank 0 after the kernel (single frame: max-rank kernel + gather)" if world > 1 else ""),
                 "partition_note": m["partition_note"],
                 "block_threads": li.block_threads,
                 "lds_bytes_per_block": li.lds_bytes,
@@ -365,6 +474,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
+                "compute": compute,
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels_per_launch,
                 "note": "12 B/pixel framebuffer store is the only HBM traffic that scales with the image; "
@@ -373,6 +484,8 @@ def main():
         }
         if grid is not None:
             out["sphere_grid"] = grid
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if world == 1 and not args.no_extra:
             # SURVEY.md 8(d) secondary figures, from the counting build at 1024 x 1024 (per-pixel counts
             # barely depend on the resolution): all rays traced, and intersection tests against the
@@ -388,8 +501,9 @@ def main():
                     "total_rays_per_s": round(pixels_per_s * rays_pp, 0),
                     "tests_issued_per_pixel": round(tests_pp, 2),
                     "tests_per_s": round(pixels_per_s * tests_pp, 0),
-                    "test_flop_frac_of_valu_peak": round(pixels_per_s * tests_pp * 15.0 / (256 * 64 * 2.4e9), 4),
-                    "note": "counting build, 1024x1024; peak = 256 CUs x 64 lanes x 2.4 GHz, one non-fused fp32 op per lane and clock",
+                    "test_flop_frac_of_valu_peak": round(pixels_per_s * tests_pp * 15.0 / VALU_PEAK_LANE_OPS, 4),
+                    "note": "counting build, 1024x1024, ~15 flop per test; peak = 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T "
+                            "non-fused fp32 lane-ops/s (MI355X_MICROARCH.md: 157.3 TF fp32 counts an FMA as two)",
                 }
             except Exception as e:
                 out["secondary_error"] = repr(e)

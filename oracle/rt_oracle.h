@@ -97,6 +97,17 @@ void orc_camera_eye_ray(const orc_camera *c, float dx, float dy, orc_vec3 *origi
 int orc_render(const orc_scene *s, const orc_camera *c, int W, int H,
                int x0, int x1, int max_depth, float *out);
 
+/* The same on n_threads host threads, the reference's static partitioning
+ * (PARTIONING_STRATEGY 1, src/RayTracer.cpp:904-923 with CORE_NUM > 1): the image
+ * sample is n_chunks chunks of chunk_cols columns starting at chunk_x0[k]
+ * (ascending), dealt to the threads in contiguous shares; chunk k lands at
+ * out + k * chunk_cols * H * 3.  cpus (may be NULL) names the logical CPU each
+ * thread is pinned to.  *seconds = wall time from "all threads ready" to "all
+ * done".  bench.py's cpu_baseline leg; rt_oracle_mt.c. */
+int orc_render_static_partition(const orc_scene *s, const orc_camera *c, int W, int H, int max_depth,
+                                const int *chunk_x0, int n_chunks, int chunk_cols,
+                                int n_threads, const int *cpus, float *out, double *seconds);
+
 /* work counters of the last orc_render on this thread (for DESIGN.md figures) */
 typedef struct orc_counters {
     unsigned long long nearest_rays, shadow_rays, collision_tests;

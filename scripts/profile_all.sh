@@ -3,7 +3,7 @@
 # Results land in gpurun_out/<dir>; scripts/save_profiles.py copies the summaries into profiles/.
 # Counters are collected in their own passes (no trace domains next to --pmc).
 set -e
-D=${1:-r01}
+D=${1:-r02}
 WHAT=${2:-all}
 R=$PWD
 O=$R/gpurun_out/$D
@@ -24,7 +24,7 @@ if [ $WHAT = all ]; then
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY -d $O/sq1 --output-format csv -- $B > $O/sq1.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d $O/sq2 --output-format csv -- $B > $O/sq2.log 2>&1
 fi
-for w in grid32; do
+for w in grid32 grid16d8; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY -d $O/sq1_$w --output-format csv -- $B --workload $w > $O/sq1_$w.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d $O/sq2_$w --output-format csv -- $B --workload $w > $O/sq2_$w.log 2>&1
 done

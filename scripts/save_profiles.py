@@ -2,7 +2,7 @@
 """Copy the summaries of a gpurun_out/<dir> profile run into profiles/."""
 import csv, glob, json, os, shutil, sys
 src = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "profiles")
 
@@ -43,6 +43,20 @@ for w, suffix in (("builtin", ""), ("grid32", "_grid32"), ("grid16d8", "_grid16d
             h, rs = rows(path)
             if path == fw: wr.writerow(h)
             wr.writerows(rs[-3:])
+sys.path.insert(0, R)
+import bench  # noqa: E402  (kernel_source_digest only)
+traffic["kernel_source_sha256"] = bench.kernel_source_digest()
+for w, dirs in (("builtin", ("sq1", "sq2")), ("grid32", ("sq1_grid32", "sq2_grid32")), ("grid16d8", ("sq1_grid16d8", "sq2_grid16d8"))):
+    c = {}
+    for d in dirs:
+        path = one(f"{d}/*/*_counter_collection.csv")
+        if path: c.update(counter(path))
+    if w in traffic and "SQ_INSTS_VALU" in c:
+        traffic[w]["sq_insts_valu"] = c["SQ_INSTS_VALU"]
+        traffic[w]["sq_insts_salu"] = c.get("SQ_INSTS_SALU")
+        traffic[w]["sq_insts_lds"] = c.get("SQ_INSTS_LDS")
+        traffic[w]["sq_waves"] = c.get("SQ_WAVES")
+        if c.get("SQ_BUSY_CYCLES"): traffic[w]["sq_busy_cycles_per_engine"] = c["SQ_BUSY_CYCLES"] / 32.0
 json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(P, f"{tag}_builtin4096d4_pmc_sq.csv"), "w") as f:
     wr = csv.writer(f)

@@ -81,6 +81,8 @@ def _load():
     L.orc_camera_eye_ray.argtypes = [C.POINTER(OrcCamera), f, f, C.POINTER(Vec3), C.POINTER(Vec3)]
     L.orc_camera_eye_ray.restype = None
     L.orc_render.argtypes = [vp, C.POINTER(OrcCamera), i, i, i, i, i, vp]
+    L.orc_render_static_partition.argtypes = [vp, C.POINTER(OrcCamera), i, i, i, C.POINTER(i), i, i, i, C.POINTER(i), vp,
+                                              C.POINTER(C.c_double)]
     L.orc_get_counters.argtypes = [C.POINTER(OrcCounters)]
     L.orc_get_counters.restype = None
     L.orc_write_screen_txt.argtypes = [C.c_char_p, i, i, vp, C.c_double, C.c_double]

@@ -107,10 +107,11 @@ def test_balanced_bounds_properties():
         for world in (1, 2, 3, 8):
             for cost in (np.full(W, 1.0 / W), rng.uniform(0.1, 2.0, W), np.r_[np.zeros(W // 2), np.ones(W - W // 2)]):
                 for send in (0.0, 0.5 * cost.mean(), 3.0 * cost.mean()):
-                    b = balanced_bounds(W, world, cost, send)
-                    assert len(b) == world and b[0][0] == 0 and b[-1][1] == W
-                    assert all(0 <= x0 <= x1 <= W for x0, x1 in b)
-                    assert all(b[r][1] == b[r + 1][0] for r in range(world - 1))
+                    for overlap in (True, False):
+                        b = balanced_bounds(W, world, cost, send, overlap=overlap)
+                        assert len(b) == world and b[0][0] == 0 and b[-1][1] == W
+                        assert all(0 <= x0 <= x1 <= W for x0, x1 in b)
+                        assert all(b[r][1] == b[r + 1][0] for r in range(world - 1))
     # nothing to send and a flat cost: the equal partition
     assert balanced_bounds(4096, 8, np.full(4096, 1.0), 0.0) == equal_bounds(4096, 8)
     # a link slower than a GPU: the receiver renders more, the peers share the rest evenly
@@ -119,6 +120,12 @@ def test_balanced_bounds_properties():
     assert widths[0] > 2 * widths[1] and max(widths[1:]) - min(widths[1:]) <= 8
     frame = max([widths[0] * 1.08 / 4096] + [w * 2.68 / 4096 for w in widths[1:]])
     assert frame < 0.30                                       # 0.335 with equal strips
+    # one frame, nothing overlapped: a peer's time is kernel + send, the receiver takes even more
+    b1 = balanced_bounds(4096, 8, np.full(4096, 1.08 / 4096), 2.68 / 4096, overlap=False)
+    w1 = [x1 - x0 for x0, x1 in b1]
+    single = max([w1[0] * 1.08 / 4096] + [w * (1.08 + 2.68) / 4096 for w in w1[1:]])
+    equal_single = 512 * (1.08 + 2.68) / 4096
+    assert w1[0] > widths[0] and single < 0.80 * equal_single
     # a costly middle: strips there get narrower
     cost = np.ones(4096)
     cost[1536:2560] = 4.0

@@ -42,12 +42,15 @@ def equal_bounds(W, world):
     return [strip_bounds(W, world, r)[:2] for r in range(world)]
 
 
-def balanced_bounds(W, world, column_cost, send_cost_per_column, root=0):
-    """Contiguous strips, in rank order, that minimise the time of a pipelined frame
-    when rendering and the gather overlap:
+def balanced_bounds(W, world, column_cost, send_cost_per_column, root=0, overlap=True):
+    """Contiguous strips, in rank order, that minimise the frame time:
 
         rank `root`:  sum of column_cost over its strip          (it sends nothing)
-        other ranks:  max(that sum, columns * send_cost_per_column)
+        other ranks:  max(that sum, columns * send_cost_per_column)   overlap=True: a pipeline of
+                      frames, the gather of frame k under the render of frame k+1
+                      that sum + columns * send_cost_per_column       overlap=False: ONE frame,
+                      a peer's columns leave after its kernel (max-rank
+                      kernel + gather)
 
     column_cost[x] is the (measured) render time of image column x on one GPU,
     send_cost_per_column the (measured) time one peer needs to deliver one column
@@ -69,9 +72,14 @@ def balanced_bounds(W, world, column_cost, send_cost_per_column, root=0):
         bounds, x = [], 0
         for r in range(world):
             # furthest x1 with prefix[x1] - prefix[x] <= limit
-            x1 = int(np.searchsorted(prefix, prefix[x] + limit, side="right")) - 1
+            if r != root and g > 0.0 and not overlap:
+                # render + send <= limit: prefix[x1] + g * x1 <= prefix[x] + g * x + limit (monotone in x1)
+                serial = prefix + g * np.arange(W + 1)
+                x1 = int(np.searchsorted(serial, serial[x] + limit, side="right")) - 1
+            else:
+                x1 = int(np.searchsorted(prefix, prefix[x] + limit, side="right")) - 1
             x1 = max(x, min(W, x1))
-            if r != root and g > 0.0:
+            if r != root and g > 0.0 and overlap:
                 x1 = min(x1, x + int(limit / g))
             bounds.append((x, x1))
             x = x1
@@ -114,7 +122,7 @@ def gather_uneven(strip_buf, views, bounds, dst=0, async_op=False):
     return works
 
 
-def measure_and_balance(pipe, W, my_kernel_ms, sync, device):
+def measure_and_balance(pipe, W, my_kernel_ms, sync, device, overlap=True):
     """Called by every rank between two warm-up frames on the EQUAL partition.
     Times one gather on its own (nothing else in flight; `sync()` must drain the
     device and end with a barrier), shares every rank's kernel time, and returns
@@ -139,7 +147,7 @@ def measure_and_balance(pipe, W, my_kernel_ms, sync, device):
         if b > a:
             cost[a:b] = max(k, 0.0) / (b - a)
     per_column_send = gather_ms / max(eq[0][1] - eq[0][0], 1)
-    bounds = balanced_bounds(W, world, cost, per_column_send)
+    bounds = balanced_bounds(W, world, cost, per_column_send, overlap=overlap)
     note = (f"re-cut after warm-up frames on the equal partition: kernel ms per rank "
             f"{[round(k, 3) for k in kernel_by_rank]}, gather alone {gather_ms:.3f} ms")
     return bounds, note
