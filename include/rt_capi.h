@@ -99,6 +99,7 @@ typedef struct rt_timing {
     uint64_t launches;          /* kernel launches accumulated                                          */
     double   last_upload_ms;    /* scene-table upload in rt_scene_create                                */
     double   last_download_ms;  /* device->host copy in rt_render (0 for rt_render_device)              */
+    double   last_second_pass_ms; /* of last_kernel_ms: the second launch (deferred tiles, sliced); 0 if none */
 } rt_timing;
 
 typedef struct rt_launch_info {
@@ -107,6 +108,9 @@ typedef struct rt_launch_info {
     int32_t scene_lds_bytes;    /* of which scene tables                                        */
     int32_t grid_blocks;        /* workgroups of the last launch                                */
     int32_t tile_x, tile_z;     /* pixels per wavefront tile (tile_x * tile_z == 64)            */
+    int32_t deferred_tiles;     /* tiles the last launch left to its second pass (-1: no second pass);
+                                   reading it waits for the launch to finish                    */
+    int32_t slices;             /* copies of each ray in a deferred tile                        */
 } rt_launch_info;
 
 /* Replaces: the Scene the reference keeps in the global my_scene
@@ -180,6 +184,14 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   nearest-first early exit, no sphere clustering, no
  *                   axis-aligned route (the slow baseline the fast path is
  *                   checked against, pixel for pixel, in tests/)
+ *   "defer"         a tile one of whose scans is left with this many candidate
+ *                   sphere-cluster leaves (1..64) by the wavefront's cull is not
+ *                   rendered in the first pass but in a second one, as `slices`
+ *                   sub-tiles whose wavefronts carry 64 / slices pixels, every
+ *                   ray in `slices` lanes that share the candidate leaves (so
+ *                   that no wavefront is kept for milliseconds by one tile);
+ *                   -1 = automatic, 0 = never
+ *   "slices"        2, 4, 8 (default) or 16; 1 = no second pass
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
  *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */
 int rt_set_option(rt_scene *scene, const char *key, int value);

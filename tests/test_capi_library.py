@@ -37,8 +37,8 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(capi.RtObjectDesc) == 4 * (4 + 3 + 3 + 3 + 2 + 3 + 12 + 2 + 1)
     assert C.sizeof(capi.RtTextureDesc) == 32
     assert C.sizeof(capi.RtCameraDesc) == 64
-    assert C.sizeof(capi.RtTiming) == 40
-    assert C.sizeof(capi.RtLaunchInfo) == 24
+    assert C.sizeof(capi.RtTiming) == 48
+    assert C.sizeof(capi.RtLaunchInfo) == 32
 
 
 def _create(desc):

@@ -631,3 +631,65 @@ def test_failed_option_leaves_the_handle_usable(oracle):
         except RtError:
             pass
         assert_same(r.render(24, 24, 3), want, f"after {key}={value}")
+
+
+# ------------------------------------------------ round 2: deferred tiles (sliced second pass)
+@pytest.mark.parametrize("slices", [2, 4, 8, 16])
+@pytest.mark.parametrize("name,W,H,depth", [("grid16", 96, 80, 8), ("grid9", 50, 120, 3), ("twomirrors", 24, 24, 4)])
+def test_sliced_tiles_do_not_change_results(oracle, name, W, H, depth, slices):
+    """rt_set_option("defer", 1): every tile with a candidate leaf in any scan goes to the second
+    pass, where a wavefront carries 64 / slices pixels and the copies of a ray share the leaves."""
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    r.set_option("defer", 1)
+    r.set_option("slices", slices)
+    assert_same(r.render(W, H, depth), want, f"{name} all deferred x{slices}")
+    assert_same(r.render(W, H, depth, 7, W - 5), want[7:W - 5], f"{name} all deferred x{slices}, strip")
+
+
+@pytest.mark.parametrize("defer,slices,tile_z", [(-1, 8, 0), (0, 8, 0), (3, 4, 0), (6, 16, 4), (2, 2, 16), (5, 8, 1), (9, 8, 64), (64, 4, 0)])
+def test_deferral_threshold_does_not_change_results(oracle, defer, slices, tile_z):
+    from scene_gen import build_sphere_field
+    host = build_sphere_field(HostScene.empty(), 11, n_spheres=150)
+    orc = build_sphere_field(oracle.OracleScene(), 11, n_spheres=150)
+    r = Renderer(host)
+    r.set_option("defer", defer)
+    r.set_option("slices", slices)
+    if tile_z:
+        r.set_option("tile_z", tile_z)
+    want = orc.render(72, 333, 4)
+    assert_same(r.render(72, 333, 4), want, f"defer {defer} slices {slices} tile_z {tile_z}")
+    assert_same(r.render(72, 333, 4, 30, 71), want[30:71], f"defer {defer} slices {slices} tile_z {tile_z}, strip")
+
+
+@pytest.mark.parametrize("seed", [21, 24, 27, 30])
+def test_sliced_tiles_on_adversarial_scenes(oracle, seed):
+    host = _adversarial(HostScene.empty(), seed)
+    orc = _adversarial(oracle.OracleScene(), seed)
+    r = Renderer(host)
+    r.set_option("defer", 1 + seed % 3)
+    r.set_option("slices", [4, 8, 2, 16][seed % 4])
+    assert_same(r.render(96, 64, 5), orc.render(96, 64, 5), f"adversarial seed {seed}, sliced")
+
+
+def test_sliced_tiles_inside_a_clustered_sphere_field(oracle):
+    """Negative-distance hits (ray origins inside spheres) through the sliced path."""
+    from scene_gen import build_sphere_field
+    def build(scene):
+        rng = np.random.RandomState(7)
+        i = scene.add_sphere((3.0, 5.0, 8.0), 0.15)
+        scene.set_light(i)
+        for k in range(80):
+            big = k % 9 == 0
+            c = (float(np.float32(rng.uniform(-2, 2))), float(np.float32(rng.uniform(-2, 6))), float(np.float32(rng.uniform(1, 4))))
+            i = scene.add_sphere(c, float(np.float32(rng.uniform(6, 12) if big else rng.uniform(0.2, 0.8))))
+            if k % 2:
+                scene.set_reflective(i, 0.5)
+        scene.add_infinite_plane((0.0, 0.0, -1.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+        scene.set_object_indices(0, 1)
+        scene.camera_two_mirrors()
+        return scene
+    want = build(oracle.OracleScene()).render(64, 64, 4)
+    r = Renderer(build(HostScene.empty()))
+    r.set_option("defer", 1)
+    assert_same(r.render(64, 64, 4), want, "inside a clustered field, sliced")

@@ -22,13 +22,34 @@
 extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__restrict__ image,
                                             float *__restrict__ out,
                                             unsigned int *__restrict__ tile_counter,
-                                            float4 *__restrict__ bounce_stack);
+                                            float4 *__restrict__ bounce_stack,
+                                            unsigned int *__restrict__ defer_list);
+
+extern "C" __global__ void rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image,
+                                                      float *__restrict__ out,
+                                                      unsigned int *__restrict__ tile_counter,
+                                                      float4 *__restrict__ bounce_stack,
+                                                      unsigned int *__restrict__ defer_list);
+
+extern "C" __global__ void rt_render_kernel_sliced(const RtParams p, const float4 *__restrict__ image,
+                                                   float *__restrict__ out,
+                                                   unsigned int *__restrict__ tile_counter,
+                                                   float4 *__restrict__ bounce_stack,
+                                                   unsigned int *__restrict__ defer_list);
+
+extern "C" __global__ void rt_render_kernel_sliced_stats(const RtParams p, const float4 *__restrict__ image,
+                                                         float *__restrict__ out,
+                                                         unsigned int *__restrict__ tile_counter,
+                                                         float4 *__restrict__ bounce_stack,
+                                                         unsigned long long *__restrict__ stats_out,
+                                                         unsigned int *__restrict__ defer_list);
 
 extern "C" __global__ void rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image,
                                                   float *__restrict__ out,
                                                   unsigned int *__restrict__ tile_counter,
                                                   float4 *__restrict__ bounce_stack,
-                                                  unsigned long long *__restrict__ stats_out);
+                                                  unsigned long long *__restrict__ stats_out,
+                                                  unsigned int *__restrict__ defer_list);
 
 namespace {
 
@@ -51,8 +72,9 @@ struct Quad { float v[4]; };
 
 float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
-struct EventPair { hipEvent_t start, stop; bool pending; };
+struct EventPair { hipEvent_t start, mid, stop; bool pending, two_passes; };
 constexpr int kEventRing = 64;
+constexpr int kCounterWords = (RT_TILE_QUEUES + 1) * RT_QUEUE_STRIDE;   /* 8 queue heads + the second pass's, own cache lines */
 
 } // namespace
 
@@ -76,6 +98,9 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
+    int defer_opt = -1;           /* a scan with this many candidate leaves defers its tile to the sliced second pass;
+                                     -1 = automatic (RT_DEFER_LEAVES when the scene has clustered runs), 0 = never */
+    int slices = RT_DEFER_SLICES; /* copies of each ray in a deferred (sliced) tile: 2, 4, 8 or 16 */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int leaf_items_opt = 1;       /* clustered runs appear in the item tables leaf by leaf (0: group by group) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
@@ -85,6 +110,9 @@ struct rt_scene {
     int n_clusters = 0;
     /* tile queue heads, one per in-flight launch (same ring as the events) */
     unsigned int *d_counters = nullptr;
+    /* defer list {count, tile, tile, ...} of the launch in flight (launches of one handle are stream-ordered) */
+    unsigned int *d_defer = nullptr;
+    size_t d_defer_words = 0;
     /* bounce stack in HBM: grid_blocks x (max_depth + 1) x block_threads entries of 16 B */
     void *d_stack = nullptr;
     size_t d_stack_bytes = 0;
@@ -462,6 +490,7 @@ int pack_scene(rt_scene *s) {
             out.push_back(q0);
             out.push_back(q1);
         };
+        b.near_first_leaf = (int)(near_items.size() / 2);
         if (s->leaf_items_opt) {
             for (const LeafItem &l : leaf_items) leaf_item(near_items, l);
         } else {
@@ -469,6 +498,7 @@ int pack_scene(rt_scene *s) {
         }
         for (int i = sb; i < se; ++i)
             if (!objs[i].is_light && !clustered[(size_t)i]) object_item(shadow_items, i);
+        b.shadow_first_leaf = (int)(shadow_items.size() / 2);
         if (s->leaf_items_opt) {
             for (const LeafItem &l : leaf_items)
                 if (l.in_shadow) leaf_item(shadow_items, l);
@@ -557,7 +587,9 @@ int ensure_events(rt_scene *s) {
     for (int i = 0; i < kEventRing; ++i) {
         HIP_TRY(hipEventCreate(&s->ev[i].start));
         HIP_TRY(hipEventCreate(&s->ev[i].stop));
+        HIP_TRY(hipEventCreate(&s->ev[i].mid));
         s->ev[i].pending = false;
+        s->ev[i].two_passes = false;
     }
     s->ev_ready = true;
     return RT_OK;
@@ -570,6 +602,12 @@ int drain_event(rt_scene *s, int i) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e.start, e.stop));
     s->timing.last_kernel_ms = ms;
+    s->timing.last_second_pass_ms = 0.0;
+    if (e.two_passes) {
+        float ms2 = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms2, e.mid, e.stop));
+        s->timing.last_second_pass_ms = ms2;
+    }
     s->timing.sum_kernel_ms += ms;
     s->timing.launches += 1;
     e.pending = false;
@@ -681,6 +719,15 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         p.first_macro_row = (int)std::min(macro_rows - 1, macro_rows * (long long)permille / 1000);
         if (p.first_macro_row < 0) p.first_macro_row = 0;
     }
+    /* deferred tiles (rt_tables.h): only scenes with clustered sphere runs have leaves to count */
+    p.pass = 0;
+    p.slice_log2 = 0;
+    p.defer_leaves = 0;
+    if (s->n_clusters > 0 && s->cull_opt && s->slices >= 1) {
+        p.defer_leaves = s->defer_opt >= 0 ? s->defer_opt : RT_DEFER_LEAVES;
+        if (p.defer_leaves > 0)
+            for (int v = s->slices; v > 1; v >>= 1) ++p.slice_log2;
+    }
     p.n_tiles = (int)n_tiles;
     const int waves_per_block = block / 64;
     const long long blocks_all = (n_tiles + waves_per_block - 1) / waves_per_block;
@@ -701,25 +748,22 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
      * workgroups simply find the queue empty), never more than there are tiles */
     if (!s->d_counters) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters),
-                          (size_t)kEventRing * RT_TILE_QUEUES * RT_QUEUE_STRIDE * sizeof(unsigned int)));
+                          (size_t)kEventRing * kCounterWords * sizeof(unsigned int)));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    /* first-pass kernel: the plain one, or the one whose tiles may defer themselves */
+    const void *first = d_stats ? (const void *)rt_render_kernel_stats
+                                : (p.defer_leaves > 0 ? (const void *)rt_render_kernel_deferring : (const void *)rt_render_kernel);
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, reinterpret_cast<const void *>(d_stats ? (const void *)rt_render_kernel_stats : (const void *)rt_render_kernel),
-        block, (size_t)lds_bytes));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, first, block, (size_t)lds_bytes));
     if (per_cu < 1) per_cu = 1;
     const long long blocks = s->grid_mult > 0
         ? std::min(blocks_all, (long long)per_cu * (long long)s->n_cus * (long long)s->grid_mult)
         : blocks_all;
     s->launch.grid_blocks = (int)blocks;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    if (d_stats)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_render_kernel_stats),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(first, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     /* bounce stack: one slice per workgroup of the persistent grid */
     {
         const double need_d = stack_lds_levels > max_depth ? 16.0
@@ -743,17 +787,57 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     rc = drain_event(s, slot);            /* ring wrapped: account for the old launch first */
     if (rc) return rc;
     s->ev_next = (s->ev_next + 1) % kEventRing;
-    unsigned int *counter = s->d_counters + (size_t)slot * RT_TILE_QUEUES * RT_QUEUE_STRIDE;
-    HIP_TRY(hipMemsetAsync(counter, 0, (size_t)RT_TILE_QUEUES * RT_QUEUE_STRIDE * sizeof(unsigned int), stream));
+    unsigned int *counter = s->d_counters + (size_t)slot * kCounterWords;
+    HIP_TRY(hipMemsetAsync(counter, 0, (size_t)kCounterWords * sizeof(unsigned int), stream));
+    if (p.defer_leaves > 0) {
+        const size_t words = 1 + (size_t)n_tiles;
+        if (words > s->d_defer_words) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (s->d_defer) { HIP_TRY(hipFree(s->d_defer)); s->d_defer = nullptr; s->d_defer_words = 0; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_defer), words * sizeof(unsigned int)));
+            s->d_defer_words = words;
+        }
+        HIP_TRY(hipMemsetAsync(s->d_defer, 0, sizeof(unsigned int), stream));      /* the count */
+    }
     HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
+    /* pass 0: every tile; pass 1 (only if tiles can defer themselves): the deferred ones, sliced.
+     * Same stream: the second launch starts when the first has drained and sees its list. */
+    s->ev[slot].two_passes = p.defer_leaves > 0;
+    s->launch.deferred_tiles = p.defer_leaves > 0 ? 0 : -1;
+    s->launch.slices = 1 << p.slice_log2;
+    p.pass = 0;
     if (d_stats)
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
                            stream, p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats);
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
+    else if (p.defer_leaves > 0)
+        hipLaunchKernelGGL(rt_render_kernel_deferring, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
+                           p, reinterpret_cast<const float4 *>(s->d_image),
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
     else
         hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack));
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+    if (p.defer_leaves > 0) {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s->ev[slot].mid, stream));
+        p.pass = 1;
+        int per_cu2 = 0;
+        const void *second = d_stats ? (const void *)rt_render_kernel_sliced_stats : (const void *)rt_render_kernel_sliced;
+        HIP_TRY(hipFuncSetAttribute(second, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, second, block, (size_t)lds_bytes));
+        if (per_cu2 < 1) per_cu2 = 1;
+        /* never more workgroups than the first pass: the bounce stack has one slice per workgroup */
+        const long long blocks2 = std::min(blocks, (long long)per_cu2 * (long long)s->n_cus);
+        if (d_stats)
+            hipLaunchKernelGGL(rt_render_kernel_sliced_stats, dim3((unsigned)blocks2), dim3((unsigned)block), (size_t)lds_bytes,
+                               stream, p, reinterpret_cast<const float4 *>(s->d_image),
+                               d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
+        else
+            hipLaunchKernelGGL(rt_render_kernel_sliced, dim3((unsigned)blocks2), dim3((unsigned)block), (size_t)lds_bytes, stream,
+                               p, reinterpret_cast<const float4 *>(s->d_image),
+                               d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
     s->ev[slot].pending = true;
@@ -805,10 +889,11 @@ int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     if (s->d_image || s->d_fb || s->d_counters || s->ev_ready) (void)hipSetDevice(s->device);
     if (s->ev_ready)
-        for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].stop); }
+        for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].mid); (void)hipEventDestroy(s->ev[i].stop); }
     if (s->d_image) (void)hipFree(s->d_image);
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_defer) (void)hipFree(s->d_defer);
     if (s->d_stack) (void)hipFree(s->d_stack);
     delete s;
     return RT_OK;
@@ -925,6 +1010,13 @@ int rt_get_launch_info(const rt_scene *s, rt_launch_info *out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "scene/out is NULL");
     *out = s->launch;
     out->scene_lds_bytes = s->base.image_quads * 16;
+    if (s->launch.deferred_tiles >= 0 && s->d_defer) {
+        unsigned int n = 0;
+        HIP_TRY(hipSetDevice(s->device));
+        if (s->has_last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
+        HIP_TRY(hipMemcpy(&n, s->d_defer, sizeof(n), hipMemcpyDeviceToHost));
+        out->deferred_tiles = (int32_t)n;
+    }
     return RT_OK;
 }
 
@@ -952,6 +1044,17 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "first_row")) {
         if (value < -1 || value > 999) return fail(RT_ERR_INVALID, "first_row is in thousandths of the image height, [0, 999], or -1 (automatic)");
         s->first_row_permille = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "defer")) {
+        if (value < -1 || value > 64) return fail(RT_ERR_INVALID, "defer is a number of candidate leaves in [1, 64], 0 (never) or -1 (automatic)");
+        s->defer_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "slices")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+            return fail(RT_ERR_INVALID, "slices must be 1 (no second pass), 2, 4, 8 or 16");
+        s->slices = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "grid_mult")) {

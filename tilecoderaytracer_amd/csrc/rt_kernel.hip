@@ -439,11 +439,55 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
     *upper_a = uniform_f(max_positive ? nan : -rmax);
 }
 
-template <bool kStats>
+/* SLICED tiles (rt_tables.h, "deferred tiles").  A wavefront of a sliced tile carries
+ * 64 >> sl.log2 rays, each in 1 << sl.log2 lanes ("copies": lane = copy * rays + ray);
+ * every copy of a ray holds identical state.  The candidate LEAVES of clustered sphere
+ * runs are dealt to the copies -- copy q takes the q-th, (q + S)-th, ... candidate leaf,
+ * box test and member tests -- and the copies are combined afterwards: the nearest hit
+ * is the minimum of (distance, Scene index) over the copies, the shadow verdict their
+ * OR.  Both are independent of the order of the tests, hence exactly what the
+ * reference's in-order scans find (src/RayTracer.cpp:71-80, 727-729).  Everything else
+ * (culls, plain items, planes, shading) runs redundantly in every copy.
+ *
+ * Unsliced tiles may DEFER themselves (kSliced == false, p.defer_leaves > 0): when the
+ * bundle cull of one of their scans leaves p.defer_leaves or more candidate leaves AND
+ * at least half of a sample of the (ray, leaf) pairs really need their leaf -- horizon
+ * rows, rays reflected to grazing directions: every ray then tests most of the scene,
+ * which keeps ONE wavefront busy for hundreds of microseconds per scan -- the scan sets
+ * *defer and the tile is abandoned before the expensive scan runs; the second pass
+ * renders it sliced. */
+/* kSliced = 0: a first-pass tile that never defers itself; 1: a sliced tile; 2: a first-pass tile that may defer */
+template <int kSliced> struct Slicing { };
+template <> struct Slicing<1> {
+    int log2;       /* wave-uniform */
+    int copy;       /* per lane     */
+};
+
+/* the value another lane holds (ds_bpermute: LDS crossbar, no memory) */
+__device__ __forceinline__ int lane_xor_i32(const int v, const int lane, const int mask) {
+    return __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, v);
+}
+
+/* Sliced tiles: pops up to 1 << log2 candidates off *mask (a wave-uniform bit set of
+ * items base + bit); copy q gets the q-th of them, -1 if there were fewer. */
+__device__ __forceinline__ int deal_candidates(unsigned long long *mask, const int base, const Slicing<1> sl) {
+    int mine = -1;
+    for (int q = 0; q < (1 << sl.log2) && *mask != 0ull; ++q) {
+        const int src = __ffsll((long long)*mask) - 1;
+        *mask &= *mask - 1ull;
+        if (sl.copy == q) mine = base + src;
+    }
+    return mine;
+}
+
+template <bool kStats, int kMode>
 __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, const bool active,
                                                   const V3 o, const V3 d, const bool have_origin_box,
                                                   const V3 origins_lo, const V3 origins_hi,
-                                                  float *best_out, int *best_idx_out, Stats<kStats> &st) {
+                                                  float *best_out, int *best_idx_out, Stats<kStats> &st,
+                                                  const Slicing<kMode> sl, bool *defer) {
+    constexpr bool kSliced = kMode == 1, kMayDefer = kMode == 2;
+    (void)kMayDefer;
     float best = 65535.0f;
     int best_idx = -1;
     st_lane(st, ST_NEAREST_RAYS, active);
@@ -549,6 +593,47 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
          * would otherwise test all of it.  The order of the tests does not change the
          * result: the winner is the minimum of (distance, Scene index), which is what
          * the reference's in-order scan with a strict `<` finds. */
+        /* which candidates are leaves of clustered runs: the items from p.near_first_leaf on */
+        if ((kSliced || kMayDefer) && p.n_clusters > 0) {
+            const int plain = min(max(p.near_first_leaf - base, 0), 64);
+            unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
+            if constexpr (!kSliced) {
+                if (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves) {
+                    /* many candidate leaves: how DENSE is the (ray, leaf) matrix?  Lane i asks whether
+                     * its own ray needs leaf i -- the diagonal, one box test for the wavefront */
+                    const bool sampled = active && ((leaf_mask >> lane) & 1ull) != 0ull;
+                    const int probe = min(base + lane, p.n_near_items - 1);
+                    const bool needed = sampled && box_needed(items[2 * probe], items[2 * probe + 1], o, inv, best);
+                    const int n_sampled = __popcll(__builtin_amdgcn_ballot_w64(sampled));
+                    if (n_sampled >= 4 && 2 * __popcll(__builtin_amdgcn_ballot_w64(needed)) >= n_sampled) { *defer = true; mask = 0ull; base = p.n_near_items; }
+                }
+            } else {
+                mask &= ~leaf_mask;
+                if (lane >= plain) key = 0xFFFFFFFFu;               /* not the ordered loop's business */
+                while (leaf_mask != 0ull) {
+                    const int mine = deal_candidates(&leaf_mask, base, sl);
+                    const int item = mine >= 0 ? mine : base;
+                    const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
+                    const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
+                    const int n = (int)((bits >> 8) & 255u);
+                    const float4 *g = lds + (bits >> 16);
+                    const uint32_t *ids = lds_u32 + bits1;
+                    st_wave(st, ST_WAVE_BOX_TESTS);
+                    const bool lane_needs = mine >= 0 && active && box_needed(i0, i1, o, inv, best);
+                    for (int i = 0; wave_any(lane_needs && i < n); ++i) {
+                        const int ic = min(i, n - 1);
+                        bool hit; float t;
+                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs && i < n);
+                        sphere_distance(g[ic], o, d, &hit, &t);
+                        hit = hit && lane_needs && i < n;
+                        if (wave_any(hit)) {
+                            const int member = (int)ids[ic];
+                            if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
+                        }
+                    }
+                }
+            }
+        }
         const bool ordered = cull && __popcll(mask) >= RT_ORDER_MIN_CANDIDATES;
         while (mask != 0ull) {
             int src;
@@ -634,6 +719,15 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             }
         }
     }
+    if constexpr (kSliced) {
+        /* the copies of a ray tested different leaves: the minimum of (distance, Scene index) */
+        for (int k = 0; k < sl.log2; ++k) {
+            const int stride = (64 >> sl.log2) << k;
+            const float ot = __int_as_float(lane_xor_i32(__float_as_int(best), lane, stride));
+            const int oi = lane_xor_i32(best_idx, lane, stride);
+            if (oi >= 0 && (best_idx < 0 || nearer(ot, oi, best, best_idx))) { best = ot; best_idx = oi; }
+        }
+    }
     *best_out = best;
     *best_idx_out = active ? best_idx : -1;
 }
@@ -664,10 +758,23 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
     *centre = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
 }
 
-template <bool kStats>
+/* OR of `blocked` over the copies of each ray of a sliced tile (all 64 lanes active) */
+__device__ __forceinline__ bool or_over_copies(const bool blocked, const int log2) {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(blocked);
+    for (int k = 0; k < log2; ++k) {
+        const int stride = (64 >> log2) << k;
+        m |= (m >> stride) | (m << (64 - stride));        /* rotations: every copy sees every other */
+    }
+    return ((m >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+}
+
+template <bool kStats, int kMode>
 __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
-                                         const V3 origins_centre, const V3 origins_half, Stats<kStats> &st) {
+                                         const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
+                                         const Slicing<kMode> sl, bool *defer) {
+    constexpr bool kSliced = kMode == 1, kMayDefer = kMode == 2;
+    (void)kMayDefer;
     bool blocked = !active;
     int stat_my_leaves = 0;
     if (p.n_shadow_items == 0) return false;
@@ -715,6 +822,40 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
+        if ((kSliced || kMayDefer) && p.n_clusters > 0) {
+            const int plain = min(max(p.shadow_first_leaf - base, 0), 64);
+            unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
+            if constexpr (!kSliced) {
+                if (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves) {        /* as in nearest_hit_items() */
+                    const bool sampled = active && ((leaf_mask >> lane) & 1ull) != 0ull;
+                    const int probe = min(base + lane, p.n_shadow_items - 1);
+                    const bool needed = sampled && box_needed(items[2 * probe], items[2 * probe + 1], o, inv, dist_to_light);
+                    const int n_sampled = __popcll(__builtin_amdgcn_ballot_w64(sampled));
+                    if (n_sampled >= 4 && 2 * __popcll(__builtin_amdgcn_ballot_w64(needed)) >= n_sampled) { *defer = true; mask = 0ull; base = p.n_shadow_items; }
+                }
+            } else {
+                mask &= ~leaf_mask;
+                while (leaf_mask != 0ull) {
+                    if (!wave_any(!blocked)) return true;
+                    const int mine = deal_candidates(&leaf_mask, base, sl);
+                    const int item = mine >= 0 ? mine : base;
+                    const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
+                    const uint32_t bits = __float_as_uint(i0.w);
+                    const int n = (int)((bits >> 8) & 255u);
+                    const float4 *g = lds + (bits >> 16);
+                    st_wave(st, ST_WAVE_BOX_TESTS);
+                    const bool lane_needs = mine >= 0 && !blocked && box_needed(i0, i1, o, inv, dist_to_light);
+                    bool mine_blocked = false;
+                    for (int i = 0; wave_any(lane_needs && !mine_blocked && i < n); ++i) {
+                        bool hit; float t;
+                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs && i < n);
+                        sphere_distance(g[min(i, n - 1)], o, d, &hit, &t);
+                        mine_blocked = mine_blocked || (lane_needs && i < n && hit && t < dist_to_light);
+                    }
+                    blocked = or_over_copies(blocked || mine_blocked, sl.log2);
+                }
+            }
+        }
         while (mask != 0ull) {
             const int item = base + (__ffsll((long long)mask) - 1);
             mask &= mask - 1ull;
@@ -841,72 +982,27 @@ __device__ __forceinline__ size_t hbm_stack_entry(const RtParams &p, const int l
     return (size_t)(row * blockDim.x + threadIdx.x);
 }
 
-template <bool kStats>
-__device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
-                                            float *__restrict__ out, unsigned int *__restrict__ tile_counter,
-                                            float4 *__restrict__ bounce_stack,
-                                            unsigned long long *__restrict__ stats_out) {
-    extern __shared__ float4 lds[];
-    Stats<kStats> st;
-    unsigned long long t_start = 0ull, t_start_real = 0ull;
-    if constexpr (kStats) {
-        for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
-    }
-
-    /* stage the scene tables: global -> LDS, once per workgroup */
-    for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
-    __syncthreads();
-
-    /* Bounce stack, [level][threadIdx.x], one 16-byte entry per reflective level
-     * per lane.  The lowest levels -- the ones nearly every chain uses -- live in
-     * LDS behind the scene tables, as many as fit while seven workgroups per CU
-     * still do; deeper levels go to this workgroup's slice of an HBM buffer,
-     * written and read coalesced. */
+/* One wavefront tile: camera rays, the bounce loop, the unwind, the store.  Returns true
+ * if the tile deferred itself (nothing stored).  kSliced: a sub-tile of a deferred tile,
+ * 64 >> slice_log2 pixels, every ray in 1 << slice_log2 lanes (Slicing above); `sub` says
+ * which part of the 64-pixel tile. */
+template <bool kStats, int kMode>
+__device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, float *__restrict__ out,
+                                            float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
+                                            Stats<kStats> &st, const int wave, const int sub,
+                                            const int my_xcc, const int steal) {
+    constexpr bool kSliced = kMode == 1, kMayDefer = kMode == 2;
+    (void)kMayDefer;
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
-
-    /* Self-scheduling (the reference's strategy 2, src/RayTracer.cpp:956-992:
-     * a shared queue of pixels; here queues of wavefront tiles).  The grid is
-     * only as large as the chip can hold and every WAVEFRONT pulls its next
-     * tile until the tiles run out, so expensive tiles (the horizon, mirror
-     * balls) cannot pile up the way a static block -> tile map lets them.
-     *
-     * XCD-aware: there is one queue per XCD (8 counters on separate cache
-     * lines, 8x less contention than one word).  The image is cut into MACRO
-     * tiles of RT_MACRO_ROWS vertically adjacent wavefront tiles; macro tile m
-     * belongs to queue m mod 8 -- horizontally adjacent macro tiles go to
-     * different XCDs, so costly image regions are dealt evenly -- and a queue
-     * hands its macro tiles out tile by tile.  The vertically adjacent tiles of
-     * a macro tile are therefore rendered at about the same time by wavefronts
-     * of ONE XCD, and their 48-byte column segments merge into whole 64-byte
-     * sectors in that XCD's L2 before they leave for HBM.  A wavefront whose
-     * own queue is empty steals from the other XCDs' queues (placement is a
-     * speed matter only; any XCC_ID value gives the same image).  All lanes are
-     * active here and every wavefront walks all 8 queues to their end, so the
-     * grid always drains. */
     const int lane = threadIdx.x & 63;
-    const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
-    const int macro_rows = (p.tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
-    const int n_macros = macro_rows * p.tiles_x;
-  for (int steal = 0; steal < RT_TILE_QUEUES; ++steal) {
-    const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
-    unsigned int *const head = tile_counter + queue * RT_QUEUE_STRIDE;
-    /* macro tiles queue, queue + 8, queue + 16, ... */
-    const int queue_len = queue < n_macros ? ((n_macros - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
-    int next_pop = 0;
-    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-   for (;;) {
-    const int pop = __builtin_amdgcn_readfirstlane(next_pop);
-    if (pop >= queue_len) break;
-    /* ask for the following tile now; the answer is only needed after this one is rendered */
-    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-    const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
-    const int queued_row = macro / p.tiles_x;
-    const int tile_col = macro - queued_row * p.tiles_x;
-    const int shifted_row = queued_row + p.first_macro_row;                         /* first_macro_row < macro_rows */
-    const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : shifted_row;
-    const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
-    if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
-    const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
+    unsigned long long t_start = 0ull, t_start_real = 0ull;
+    const int tile_row = wave / p.tiles_x;                  /* tile number, row-major */
+    const int tile_col = wave - tile_row * p.tiles_x;
+    Slicing<kMode> sl;
+    if constexpr (kSliced) { sl.log2 = p.slice_log2; sl.copy = lane >> (6 - p.slice_log2); }
+    bool defer = false;
+    /* pixel of the tile this lane works on: all 64 of them, or the sub-tile's share */
+#define RT_TILE_PIXEL() (kSliced ? ((here(sub) << (6 - here(p.slice_log2))) + (lane & ((64 >> here(p.slice_log2)) - 1))) : lane)
     unsigned int tile_sphere0 = 0u, tile_box0 = 0u;
     if constexpr (kStats) {
         tile_sphere0 = st.c[ST_WAVE_SPHERE_TESTS]; tile_box0 = st.c[ST_WAVE_BOX_TESTS];
@@ -917,8 +1013,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     /* pixel of this lane: wavefront tiles are tile_x columns by tile_z rows;
      * consecutive lanes walk z, the contiguous axis of pixels[x][z] */
     const int tzl_a = here(p.tile_z_log2);
-    const int x = p.x0 + tile_col * (64 >> tzl_a) + (lane >> tzl_a);
-    const int z = (tile_row << tzl_a) + (lane & ((1 << tzl_a) - 1));
+    const int pix_a = RT_TILE_PIXEL();
+    const int x = p.x0 + tile_col * (64 >> tzl_a) + (pix_a >> tzl_a);
+    const int z = (tile_row << tzl_a) + (pix_a & ((1 << tzl_a) - 1));
     const bool inside = (x < p.x1) && (z < p.H);
 
     /* Camera::createEyeRay, src/Camera.cpp:71-84, with dx = (float)x / W,
@@ -955,7 +1052,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
         const unsigned long long t_scan = st_clock<kStats>();
-        nearest_hit_items<kStats>(p, lds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);   /* whole wavefront, converged */
+        nearest_hit_items<kStats, kMode>(p, lds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, sl, &defer);   /* whole wavefront, converged */
+        if (kMayDefer && defer) alive = false;                /* deferred: nothing more to trace, nothing to store */
         st_cycles(st, ST_CYCLES_NEAREST, t_scan);
         const unsigned long long t_winner = st_clock<kStats>();
         if (alive) {
@@ -1030,7 +1128,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
-                const bool blocked = in_shade<kStats>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
+                const bool blocked = in_shade<kStats, kMode>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, sl, &defer);
+                if (kMayDefer && defer) { shade = false; alive = false; }
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
                     /* the winner's material, re-read here rather than kept in registers across the shadow scan */
@@ -1114,10 +1213,14 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         }
     }
 
-    if (inside) {
+    bool stores = inside;
+    if constexpr (kSliced) stores = inside && sl.copy == 0;   /* one copy of each ray stores */
+    else if constexpr (kMayDefer) stores = inside && !defer;
+    if (stores) {
         const int tzl_b = here(p.tile_z_log2);
-        const int sx = tile_col * (64 >> tzl_b) + (lane >> tzl_b);   /* x - x0 */
-        const int sz = (tile_row << tzl_b) + (lane & ((1 << tzl_b) - 1));
+        const int pix_b = RT_TILE_PIXEL();
+        const int sx = here(tile_col) * (64 >> tzl_b) + (pix_b >> tzl_b);   /* x - x0 */
+        const int sz = (here(tile_row) << tzl_b) + (pix_b & ((1 << tzl_b) - 1));
         float *dst = out + ((size_t)sx * (size_t)p.H + (size_t)sz) * 3;
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
     }
@@ -1127,7 +1230,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
          * (the totals are added up once per wavefront, after its last tile) */
         {
             unsigned long long *rec = stats_out + ST_COUNT + (size_t)wave * RT_TILE_STATS;
-            if (lane == 0) {
+            if (lane == 0 && (!kSliced || sub == 0)) {               /* a sliced tile reports its first sub-tile */
                 rec[0] = __builtin_amdgcn_s_memtime() - t_start;
                 rec[4] = t_start_real;                               /* 100 MHz constant clock */
                 rec[5] = __builtin_amdgcn_s_memrealtime();
@@ -1138,8 +1241,100 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 
         }
     }
+    return defer;
+#undef RT_TILE_PIXEL
+}
+
+template <bool kStats, bool kSecondPass, bool kMayDefer>
+__device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
+                                            float *__restrict__ out, unsigned int *__restrict__ tile_counter,
+                                            float4 *__restrict__ bounce_stack,
+                                            unsigned long long *__restrict__ stats_out,
+                                            unsigned int *__restrict__ defer_list) {
+    extern __shared__ float4 lds[];
+    if (kSecondPass && defer_list[0] == 0u) return;          /* nothing was deferred */
+    Stats<kStats> st;
+    if constexpr (kStats) {
+        for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
+    }
+
+    /* stage the scene tables: global -> LDS, once per workgroup */
+    for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
+    __syncthreads();
+
+    /* Bounce stack, [level][threadIdx.x], one 16-byte entry per reflective level
+     * per lane.  The lowest levels -- the ones nearly every chain uses -- live in
+     * LDS behind the scene tables, as many as fit while seven workgroups per CU
+     * still do; deeper levels go to this workgroup's slice of an HBM buffer,
+     * written and read coalesced. */
+
+    /* Self-scheduling (the reference's strategy 2, src/RayTracer.cpp:956-992:
+     * a shared queue of pixels; here queues of wavefront tiles).  The grid is
+     * only as large as the chip can hold and every WAVEFRONT pulls its next
+     * tile until the tiles run out, so expensive tiles (the horizon, mirror
+     * balls) cannot pile up the way a static block -> tile map lets them.
+     *
+     * XCD-aware: there is one queue per XCD (8 counters on separate cache
+     * lines, 8x less contention than one word).  The image is cut into MACRO
+     * tiles of RT_MACRO_ROWS vertically adjacent wavefront tiles; macro tile m
+     * belongs to queue m mod 8 -- horizontally adjacent macro tiles go to
+     * different XCDs, so costly image regions are dealt evenly -- and a queue
+     * hands its macro tiles out tile by tile.  The vertically adjacent tiles of
+     * a macro tile are therefore rendered at about the same time by wavefronts
+     * of ONE XCD, and their 48-byte column segments merge into whole 64-byte
+     * sectors in that XCD's L2 before they leave for HBM.  A wavefront whose
+     * own queue is empty steals from the other XCDs' queues (placement is a
+     * speed matter only; any XCC_ID value gives the same image).  All lanes are
+     * active here and every wavefront walks all 8 queues to their end, so the
+     * grid always drains.
+     *
+     * Two passes (rt_tables.h, "deferred tiles"): pass 0 as above; a tile that defers
+     * itself is appended to defer_list.  Pass 1 -- a second launch, after the first has
+     * drained -- deals the listed tiles' sub-tiles from one counter. */
+    const int lane = threadIdx.x & 63;
+    const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
+  if constexpr (kSecondPass) {
+    const int n_sub = (int)defer_list[0] << p.slice_log2;
+    unsigned int *const head = tile_counter + RT_TILE_QUEUES * RT_QUEUE_STRIDE;
+    int next_pop = 0;
+    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+    for (;;) {
+        const int pop = __builtin_amdgcn_readfirstlane(next_pop);
+        if (pop >= n_sub) break;
+        if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+        const int tile = (int)defer_list[1 + (pop >> p.slice_log2)];
+        (void)render_tile<kStats, 1>(p, lds, out, bounce_stack, stats_out, st, tile, pop & ((1 << p.slice_log2) - 1), my_xcc, 0);
+    }
+  } else {
+    const int macro_rows = (p.tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
+    const int n_macros = macro_rows * p.tiles_x;
+  for (int steal = 0; steal < RT_TILE_QUEUES; ++steal) {
+    const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
+    unsigned int *const head = tile_counter + queue * RT_QUEUE_STRIDE;
+    /* macro tiles queue, queue + 8, queue + 16, ... */
+    const int queue_len = queue < n_macros ? ((n_macros - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
+    int next_pop = 0;
+    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+   for (;;) {
+    const int pop = __builtin_amdgcn_readfirstlane(next_pop);
+    if (pop >= queue_len) break;
+    /* ask for the following tile now; the answer is only needed after this one is rendered */
+    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+    const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
+    const int queued_row = macro / p.tiles_x;
+    const int tile_col = macro - queued_row * p.tiles_x;
+    const int shifted_row = queued_row + p.first_macro_row;                         /* first_macro_row < macro_rows */
+    const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : shifted_row;
+    const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
+    if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
+    const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
+    if (render_tile<kStats, kMayDefer ? 2 : 0>(p, lds, out, bounce_stack, stats_out, st, wave, 0, my_xcc, steal)) {
+        /* the tile deferred itself: the second pass renders it */
+        if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
+    }
    }  /* next tile of this queue */
   }   /* next queue */
+  }
     if constexpr (kStats) {
         for (int k = 0; k < ST_COUNT; ++k)
             if (st.c[k]) atomicAdd(&stats_out[k], (unsigned long long)st.c[k]);
@@ -1153,14 +1348,39 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
 rt_render_kernel(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
-                 unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack) {
-    render_body<false>(p, image, out, tile_counter, bounce_stack, nullptr);
+                 unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                 unsigned int *__restrict__ defer_list) {
+    render_body<false, false, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
-/* the counting build: same arithmetic and control flow plus work counters */
+/* the first pass for scenes whose tiles may defer themselves (clustered sphere runs) ... */
+extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
+rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+                           unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                           unsigned int *__restrict__ defer_list) {
+    render_body<false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+}
+
+/* ... and the second pass: the deferred tiles, sliced (its own kernel: the per-lane leaf records
+ * need more registers than the seven-wavefront budget of the first pass holds) */
+extern "C" __global__ void __launch_bounds__(256, 5)
+rt_render_kernel_sliced(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+                        unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                        unsigned int *__restrict__ defer_list) {
+    render_body<false, true, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+}
+
+/* the counting builds: same arithmetic and control flow plus work counters */
 extern "C" __global__ void __launch_bounds__(512)
 rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
                        unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                       unsigned long long *__restrict__ stats_out) {
-    render_body<true>(p, image, out, tile_counter, bounce_stack, stats_out);
+                       unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
+    render_body<true, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
+}
+
+extern "C" __global__ void __launch_bounds__(512)
+rt_render_kernel_sliced_stats(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+                              unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                              unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
+    render_body<true, true, false>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
 }

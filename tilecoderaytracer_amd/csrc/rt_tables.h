@@ -107,6 +107,13 @@
 #endif
 #define RT_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)   /* s_getreg_b32 HW_REG_XCC_ID, bits [3:0] */
 
+#ifndef RT_DEFER_LEAVES
+#define RT_DEFER_LEAVES 0            /* automatic: a scan with this many candidate leaves, half of them needed by the sampled rays, defers its tile */
+#endif
+#ifndef RT_DEFER_SLICES
+#define RT_DEFER_SLICES 8            /* copies of each ray in a deferred (sliced) tile */
+#endif
+
 #define RT_NEAR_CULL_MIN_ITEMS 8     /* below this many items the nearest scan skips the bundle cull */
 #define RT_SHADOW_CULL_MIN_ITEMS 8   /* below this many shadow items the wavefront skips the bundle-box cull */
 
@@ -127,6 +134,7 @@ typedef struct RtParams {
     int32_t n_shadow_items, shadow_items_off;            /* shadow item table (quads), see below */
     int32_t n_near_items, near_items_off;                /* nearest-hit item table                      */
     int32_t n_clusters;                                  /* leaves of clustered sphere runs       */
+    int32_t near_first_leaf, shadow_first_leaf;          /* item tables: the leaf items are the ones from this index on (the tables' ends if none) */
     int32_t image_quads;                 /* quads staged into LDS */
     int32_t lights_off, mat_off, tex_off, objinfo_off;   /* quad offsets */
     /* tiling: a wavefront renders tile_x x tile_z pixels, tile_x * tile_z == 64 */
@@ -136,6 +144,12 @@ typedef struct RtParams {
     int32_t n_tiles;                     /* total wavefront tiles   */
     int32_t stack_lds_levels;            /* bounce levels below this keep their stack entries in LDS (behind the tables), the others in HBM */
     int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around */
+    /* Deferred tiles.  pass 0 renders every tile with one pixel per lane, except that a tile one of
+     * whose scans is left with >= defer_leaves candidate leaves by its bundle cull (0: never) abandons
+     * itself and appends its number to the defer list {count, tile, tile, ...}.  pass 1 (a second
+     * launch on the same stream) renders the listed tiles SLICED: 1 << slice_log2 sub-tiles of
+     * 64 >> slice_log2 pixels, each ray in 1 << slice_log2 lanes that share the candidate leaves. */
+    int32_t defer_leaves, pass, slice_log2;
     int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
 } RtParams;
 
