@@ -99,7 +99,7 @@ typedef struct rt_timing {
     uint64_t launches;          /* kernel launches accumulated                                          */
     double   last_upload_ms;    /* scene-table upload in rt_scene_create                                */
     double   last_download_ms;  /* device->host copy in rt_render (0 for rt_render_device)              */
-    double   last_second_pass_ms; /* of last_kernel_ms: the second launch (deferred tiles, sliced); 0 if none */
+    double   last_second_pass_ms; /* of last_kernel_ms: the second launch (deferred tiles); 0 if none */
 } rt_timing;
 
 typedef struct rt_launch_info {
@@ -110,7 +110,7 @@ typedef struct rt_launch_info {
     int32_t tile_x, tile_z;     /* pixels per wavefront tile (tile_x * tile_z == 64)            */
     int32_t deferred_tiles;     /* tiles the last launch left to its second pass (-1: no second pass);
                                    reading it waits for the launch to finish                    */
-    int32_t slices;             /* copies of each ray in a deferred tile                        */
+    int32_t slices;             /* wavefronts that share a deferred tile's leaves in the second pass */
 } rt_launch_info;
 
 /* Replaces: the Scene the reference keeps in the global my_scene
@@ -185,13 +185,14 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   axis-aligned route (the slow baseline the fast path is
  *                   checked against, pixel for pixel, in tests/)
  *   "defer"         a tile one of whose scans is left with this many candidate
- *                   sphere-cluster leaves (1..64) by the wavefront's cull is not
- *                   rendered in the first pass but in a second one, as `slices`
- *                   sub-tiles whose wavefronts carry 64 / slices pixels, every
- *                   ray in `slices` lanes that share the candidate leaves (so
- *                   that no wavefront is kept for milliseconds by one tile);
- *                   -1 = automatic, 0 = never
- *   "slices"        2, 4, 8 (default) or 16; 1 = no second pass
+ *                   sphere-cluster leaves (1..64) by the wavefront's cull, most of
+ *                   them needed by some ray, is not rendered in the first pass but
+ *                   in a second one, where a whole workgroup renders it and its
+ *                   wavefronts share the leaves of every scan (so that no
+ *                   wavefront is kept for milliseconds by one tile);
+ *                   -1 = automatic (on when the launch renders a strip of the image,
+ *                   off for whole frames), 0 = never, 65 = every tile that has a candidate
+ *                   leaf at all (exercises the second pass in tests)
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
  *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */
 int rt_set_option(rt_scene *scene, const char *key, int value);

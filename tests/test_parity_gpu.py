@@ -633,48 +633,51 @@ def test_failed_option_leaves_the_handle_usable(oracle):
         assert_same(r.render(24, 24, 3), want, f"after {key}={value}")
 
 
-# ------------------------------------------------ round 2: deferred tiles (sliced second pass)
-@pytest.mark.parametrize("slices", [2, 4, 8, 16])
+# ------------------------------------------------ round 2: deferred tiles (workgroup-cooperative second pass)
+@pytest.mark.parametrize("block", [64, 128, 192, 256, 512, 0])
 @pytest.mark.parametrize("name,W,H,depth", [("grid16", 96, 80, 8), ("grid9", 50, 120, 3), ("twomirrors", 24, 24, 4)])
-def test_sliced_tiles_do_not_change_results(oracle, name, W, H, depth, slices):
-    """rt_set_option("defer", 1): every tile with a candidate leaf in any scan goes to the second
-    pass, where a wavefront carries 64 / slices pixels and the copies of a ray share the leaves."""
+def test_second_pass_does_not_change_results(oracle, name, W, H, depth, block):
+    """rt_set_option("defer", 65): every tile one of whose scans has a candidate leaf goes to the
+    second pass, where a workgroup of block / 64 wavefronts renders it and the wavefronts share the
+    leaves of every scan."""
     want = oracle.OracleScene.named(name).render(W, H, depth)
     r = Renderer(HostScene.named(name))
-    r.set_option("defer", 1)
-    r.set_option("slices", slices)
-    assert_same(r.render(W, H, depth), want, f"{name} all deferred x{slices}")
-    assert_same(r.render(W, H, depth, 7, W - 5), want[7:W - 5], f"{name} all deferred x{slices}, strip")
+    r.set_option("defer", 65)
+    r.set_option("second_block", block)
+    assert_same(r.render(W, H, depth), want, f"{name} deferred, {block // 64} wavefronts")
+    li = r.launch_info()
+    assert li.deferred_tiles > 0 and li.slices == (block or 256) // 64
+    assert_same(r.render(W, H, depth, 7, W - 5), want[7:W - 5], f"{name} deferred, {block // 64} wavefronts, strip")
 
 
-@pytest.mark.parametrize("defer,slices,tile_z", [(-1, 8, 0), (0, 8, 0), (3, 4, 0), (6, 16, 4), (2, 2, 16), (5, 8, 1), (9, 8, 64), (64, 4, 0)])
-def test_deferral_threshold_does_not_change_results(oracle, defer, slices, tile_z):
+@pytest.mark.parametrize("defer,block,tile_z", [(-1, 0, 0), (0, 0, 0), (3, 128, 0), (6, 256, 4), (2, 64, 16), (5, 192, 1), (9, 0, 64), (64, 0, 0), (65, 0, 8)])
+def test_deferral_threshold_does_not_change_results(oracle, defer, block, tile_z):
     from scene_gen import build_sphere_field
     host = build_sphere_field(HostScene.empty(), 11, n_spheres=150)
     orc = build_sphere_field(oracle.OracleScene(), 11, n_spheres=150)
     r = Renderer(host)
     r.set_option("defer", defer)
-    r.set_option("slices", slices)
+    if block:
+        r.set_option("second_block", block)
+        r.set_option("block_threads", min(block, 256))
     if tile_z:
         r.set_option("tile_z", tile_z)
     want = orc.render(72, 333, 4)
-    assert_same(r.render(72, 333, 4), want, f"defer {defer} slices {slices} tile_z {tile_z}")
-    assert_same(r.render(72, 333, 4, 30, 71), want[30:71], f"defer {defer} slices {slices} tile_z {tile_z}, strip")
+    assert_same(r.render(72, 333, 4), want, f"defer {defer} block {block} tile_z {tile_z}")
+    assert_same(r.render(72, 333, 4, 30, 71), want[30:71], f"defer {defer} block {block} tile_z {tile_z}, strip")
 
 
 @pytest.mark.parametrize("seed", [21, 24, 27, 30])
-def test_sliced_tiles_on_adversarial_scenes(oracle, seed):
+def test_second_pass_on_adversarial_scenes(oracle, seed):
     host = _adversarial(HostScene.empty(), seed)
     orc = _adversarial(oracle.OracleScene(), seed)
     r = Renderer(host)
-    r.set_option("defer", 1 + seed % 3)
-    r.set_option("slices", [4, 8, 2, 16][seed % 4])
-    assert_same(r.render(96, 64, 5), orc.render(96, 64, 5), f"adversarial seed {seed}, sliced")
+    r.set_option("defer", [65, 1, 65, 2][seed % 4])
+    assert_same(r.render(96, 64, 5), orc.render(96, 64, 5), f"adversarial seed {seed}, deferred")
 
 
-def test_sliced_tiles_inside_a_clustered_sphere_field(oracle):
-    """Negative-distance hits (ray origins inside spheres) through the sliced path."""
-    from scene_gen import build_sphere_field
+def test_second_pass_inside_a_clustered_sphere_field(oracle):
+    """Negative-distance hits (ray origins inside spheres) through the shared-leaf path."""
     def build(scene):
         rng = np.random.RandomState(7)
         i = scene.add_sphere((3.0, 5.0, 8.0), 0.15)
@@ -691,5 +694,6 @@ def test_sliced_tiles_inside_a_clustered_sphere_field(oracle):
         return scene
     want = build(oracle.OracleScene()).render(64, 64, 4)
     r = Renderer(build(HostScene.empty()))
-    r.set_option("defer", 1)
-    assert_same(r.render(64, 64, 4), want, "inside a clustered field, sliced")
+    r.set_option("defer", 65)
+    assert_same(r.render(64, 64, 4), want, "inside a clustered field, deferred")
+    assert r.launch_info().deferred_tiles > 0

@@ -31,13 +31,13 @@ extern "C" __global__ void rt_render_kernel_deferring(const RtParams p, const fl
                                                       float4 *__restrict__ bounce_stack,
                                                       unsigned int *__restrict__ defer_list);
 
-extern "C" __global__ void rt_render_kernel_sliced(const RtParams p, const float4 *__restrict__ image,
+extern "C" __global__ void rt_render_kernel_second(const RtParams p, const float4 *__restrict__ image,
                                                    float *__restrict__ out,
                                                    unsigned int *__restrict__ tile_counter,
                                                    float4 *__restrict__ bounce_stack,
                                                    unsigned int *__restrict__ defer_list);
 
-extern "C" __global__ void rt_render_kernel_sliced_stats(const RtParams p, const float4 *__restrict__ image,
+extern "C" __global__ void rt_render_kernel_second_stats(const RtParams p, const float4 *__restrict__ image,
                                                          float *__restrict__ out,
                                                          unsigned int *__restrict__ tile_counter,
                                                          float4 *__restrict__ bounce_stack,
@@ -98,9 +98,10 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
-    int defer_opt = -1;           /* a scan with this many candidate leaves defers its tile to the sliced second pass;
-                                     -1 = automatic (RT_DEFER_LEAVES when the scene has clustered runs), 0 = never */
-    int slices = RT_DEFER_SLICES; /* copies of each ray in a deferred (sliced) tile: 2, 4, 8 or 16 */
+    int second_block_opt = 0;     /* threads per workgroup of the second pass: 0 = as the first pass, else 64..512 */
+    int defer_opt = -1;           /* a scan with this many candidate leaves (most of them needed by some ray) defers its tile
+                                     to the second, workgroup-cooperative pass; -1 = automatic (RT_DEFER_LEAVES when the
+                                     scene has clustered runs), 0 = never */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int leaf_items_opt = 1;       /* clustered runs appear in the item tables leaf by leaf (0: group by group) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
@@ -698,6 +699,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.shw = cam->screen_halfwidth; p.shh = cam->screen_halfheight;
     p.W = W; p.H = H; p.x0 = x0; p.x1 = x1; p.max_depth = max_depth;
     p.stack_lds_levels = stack_lds_levels;
+    p.stack_stride = block;
     p.cull = s->cull_opt;
     /* Wavefront tile shape (speed only).  4 x 16 (x by z) makes every lane-row's
      * stores whole 64-byte sectors (16 pixels x 12 B = 192 B, aligned): measured
@@ -715,19 +717,35 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.tiles_x = (int)tiles_x;
     {
         const long long macro_rows = (tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
-        const int permille = s->first_row_permille >= 0 ? s->first_row_permille : horizon_start(s, cam);
+        /* Automatic order for scenes with a horizon and clustered sphere runs: start a little ABOVE the
+         * horizon row and go DOWN -- the horizon rows are the most expensive of the frame, the rows
+         * below them (the ground, with the spheres on it) get cheaper towards the bottom, and the rows
+         * above the horizon, which come last after the wrap-around, are the cheapest: the queues then
+         * hand out tiles roughly in order of decreasing cost, which keeps the tail of a frame -- or of
+         * a GPU's strip of it -- short.  "first_row" given: from there upwards, as before. */
+        const int horizon = horizon_start(s, cam);                    /* thousandths of the image height; 8 below the horizon row; 0 = none */
+        const bool automatic = s->first_row_permille < 0 && horizon > 0;
+        const int permille = s->first_row_permille >= 0 ? s->first_row_permille : (automatic ? std::min(999, horizon + 8 + 30) : 0);
+        p.rows_downwards = automatic ? 1 : 0;
         p.first_macro_row = (int)std::min(macro_rows - 1, macro_rows * (long long)permille / 1000);
         if (p.first_macro_row < 0) p.first_macro_row = 0;
     }
     /* deferred tiles (rt_tables.h): only scenes with clustered sphere runs have leaves to count */
-    p.pass = 0;
-    p.slice_log2 = 0;
     p.defer_leaves = 0;
-    if (s->n_clusters > 0 && s->cull_opt && s->slices >= 1) {
-        p.defer_leaves = s->defer_opt >= 0 ? s->defer_opt : RT_DEFER_LEAVES;
-        if (p.defer_leaves > 0)
-            for (int v = s->slices; v > 1; v >>= 1) ++p.slice_log2;
-    }
+    p.coop_off = 0;
+    if (s->n_clusters > 0 && s->cull_opt)
+        /* automatic: only when the launch renders a STRIP of the image (one GPU's share of a frame): there
+         * the strip cannot finish before its longest tile, and the second pass cuts that tile to a quarter;
+         * on a whole frame the heavy tiles are simply handed out first, and the second pass would only
+         * cost its own overhead (measured: +13 % on the 1 024-sphere grid frame) */
+        p.defer_leaves = s->defer_opt == 65 ? -1 : (s->defer_opt >= 0 ? s->defer_opt : ((x1 - x0) < W ? RT_DEFER_LEAVES : 0));
+    /* the second pass's workgroups: more wavefronts per tile (option "second_block", default: as many as the first pass);
+     * only the leader keeps a bounce stack; the cooperation area sits behind tables and stack */
+    const int block2 = s->second_block_opt ? s->second_block_opt : block;
+    const int stack_lds_levels2 = stack_lds_levels;              /* same levels in LDS, for 64 threads only */
+    const int coop_off = s->base.image_quads + stack_lds_levels2 * 64;
+    const size_t lds_bytes2 = ((size_t)coop_off + RT_COOP_QUADS(block2 / 64)) * 16;
+    if (lds_bytes2 > RT_MAX_LDS_BYTES) p.defer_leaves = 0;      /* no room for the second pass's LDS area */
     p.n_tiles = (int)n_tiles;
     const int waves_per_block = block / 64;
     const long long blocks_all = (n_tiles + waves_per_block - 1) / waves_per_block;
@@ -755,7 +773,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     }
     /* first-pass kernel: the plain one, or the one whose tiles may defer themselves */
     const void *first = d_stats ? (const void *)rt_render_kernel_stats
-                                : (p.defer_leaves > 0 ? (const void *)rt_render_kernel_deferring : (const void *)rt_render_kernel);
+                                : (p.defer_leaves != 0 ? (const void *)rt_render_kernel_deferring : (const void *)rt_render_kernel);
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, first, block, (size_t)lds_bytes));
     if (per_cu < 1) per_cu = 1;
@@ -789,7 +807,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     s->ev_next = (s->ev_next + 1) % kEventRing;
     unsigned int *counter = s->d_counters + (size_t)slot * kCounterWords;
     HIP_TRY(hipMemsetAsync(counter, 0, (size_t)kCounterWords * sizeof(unsigned int), stream));
-    if (p.defer_leaves > 0) {
+    if (p.defer_leaves != 0) {
         const size_t words = 1 + (size_t)n_tiles;
         if (words > s->d_defer_words) {
             HIP_TRY(hipDeviceSynchronize());
@@ -800,17 +818,16 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         HIP_TRY(hipMemsetAsync(s->d_defer, 0, sizeof(unsigned int), stream));      /* the count */
     }
     HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
-    /* pass 0: every tile; pass 1 (only if tiles can defer themselves): the deferred ones, sliced.
+    /* first pass: every tile; second pass (only if tiles can defer themselves): the deferred ones, one per workgroup.
      * Same stream: the second launch starts when the first has drained and sees its list. */
-    s->ev[slot].two_passes = p.defer_leaves > 0;
-    s->launch.deferred_tiles = p.defer_leaves > 0 ? 0 : -1;
-    s->launch.slices = 1 << p.slice_log2;
-    p.pass = 0;
+    s->ev[slot].two_passes = p.defer_leaves != 0;
+    s->launch.deferred_tiles = p.defer_leaves != 0 ? 0 : -1;
+    s->launch.slices = block2 / 64;
     if (d_stats)
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
                            stream, p, reinterpret_cast<const float4 *>(s->d_image),
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
-    else if (p.defer_leaves > 0)
+    else if (p.defer_leaves != 0)
         hipLaunchKernelGGL(rt_render_kernel_deferring, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
@@ -818,23 +835,25 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
-    if (p.defer_leaves > 0) {
+    if (p.defer_leaves != 0) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev[slot].mid, stream));
-        p.pass = 1;
+        p.coop_off = coop_off;
+        p.stack_lds_levels = stack_lds_levels2;
+        p.stack_stride = 64;
         int per_cu2 = 0;
-        const void *second = d_stats ? (const void *)rt_render_kernel_sliced_stats : (const void *)rt_render_kernel_sliced;
-        HIP_TRY(hipFuncSetAttribute(second, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, second, block, (size_t)lds_bytes));
+        const void *second = d_stats ? (const void *)rt_render_kernel_second_stats : (const void *)rt_render_kernel_second;
+        HIP_TRY(hipFuncSetAttribute(second, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes2));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, second, block2, lds_bytes2));
         if (per_cu2 < 1) per_cu2 = 1;
         /* never more workgroups than the first pass: the bounce stack has one slice per workgroup */
         const long long blocks2 = std::min(blocks, (long long)per_cu2 * (long long)s->n_cus);
         if (d_stats)
-            hipLaunchKernelGGL(rt_render_kernel_sliced_stats, dim3((unsigned)blocks2), dim3((unsigned)block), (size_t)lds_bytes,
+            hipLaunchKernelGGL(rt_render_kernel_second_stats, dim3((unsigned)blocks2), dim3((unsigned)block2), lds_bytes2,
                                stream, p, reinterpret_cast<const float4 *>(s->d_image),
                                d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
         else
-            hipLaunchKernelGGL(rt_render_kernel_sliced, dim3((unsigned)blocks2), dim3((unsigned)block), (size_t)lds_bytes, stream,
+            hipLaunchKernelGGL(rt_render_kernel_second, dim3((unsigned)blocks2), dim3((unsigned)block2), lds_bytes2, stream,
                                p, reinterpret_cast<const float4 *>(s->d_image),
                                d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
     }
@@ -1046,15 +1065,15 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         s->first_row_permille = value;
         return RT_OK;
     }
-    if (!std::strcmp(key, "defer")) {
-        if (value < -1 || value > 64) return fail(RT_ERR_INVALID, "defer is a number of candidate leaves in [1, 64], 0 (never) or -1 (automatic)");
-        s->defer_opt = value;
+    if (!std::strcmp(key, "second_block")) {
+        if (value != 0 && (value < 64 || value > 512 || (value % 64) != 0))
+            return fail(RT_ERR_INVALID, "second_block must be 0 (auto) or a multiple of 64 up to 512");
+        s->second_block_opt = value;
         return RT_OK;
     }
-    if (!std::strcmp(key, "slices")) {
-        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
-            return fail(RT_ERR_INVALID, "slices must be 1 (no second pass), 2, 4, 8 or 16");
-        s->slices = value;
+    if (!std::strcmp(key, "defer")) {
+        if (value < -1 || value > 65) return fail(RT_ERR_INVALID, "defer is a number of candidate leaves in [1, 64], 0 (never), -1 (automatic) or 65 (every tile with a candidate leaf)");
+        s->defer_opt = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "grid_mult")) {

@@ -439,55 +439,133 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
     *upper_a = uniform_f(max_positive ? nan : -rmax);
 }
 
-/* SLICED tiles (rt_tables.h, "deferred tiles").  A wavefront of a sliced tile carries
- * 64 >> sl.log2 rays, each in 1 << sl.log2 lanes ("copies": lane = copy * rays + ray);
- * every copy of a ray holds identical state.  The candidate LEAVES of clustered sphere
- * runs are dealt to the copies -- copy q takes the q-th, (q + S)-th, ... candidate leaf,
- * box test and member tests -- and the copies are combined afterwards: the nearest hit
- * is the minimum of (distance, Scene index) over the copies, the shadow verdict their
- * OR.  Both are independent of the order of the tests, hence exactly what the
- * reference's in-order scans find (src/RayTracer.cpp:71-80, 727-729).  Everything else
- * (culls, plain items, planes, shading) runs redundantly in every copy.
- *
- * Unsliced tiles may DEFER themselves (kSliced == false, p.defer_leaves > 0): when the
- * bundle cull of one of their scans leaves p.defer_leaves or more candidate leaves AND
- * at least half of a sample of the (ray, leaf) pairs really need their leaf -- horizon
- * rows, rays reflected to grazing directions: every ray then tests most of the scene,
- * which keeps ONE wavefront busy for hundreds of microseconds per scan -- the scan sets
- * *defer and the tile is abandoned before the expensive scan runs; the second pass
- * renders it sliced. */
-/* kSliced = 0: a first-pass tile that never defers itself; 1: a sliced tile; 2: a first-pass tile that may defer */
-template <int kSliced> struct Slicing { };
-template <> struct Slicing<1> {
-    int log2;       /* wave-uniform */
-    int copy;       /* per lane     */
-};
+/* DEFERRED tiles (rt_tables.h).  A first-pass tile (kMode 2) may defer itself: when the
+ * bundle cull of one of its scans leaves p.defer_leaves or more candidate leaves of
+ * clustered sphere runs AND some ray of a sample really needs most of the leaves it is
+ * asked about -- horizon rows, rays reflected to grazing directions: such a ray tests
+ * most of the scene, which keeps ONE wavefront busy for hundreds of microseconds per
+ * scan -- the scan sets *defer and the tile is abandoned before the expensive scan runs.
+ * The second pass renders the deferred tiles with whole workgroups (kMode 3): wavefront
+ * 0, the LEADER, renders the tile exactly like a first-pass tile, except that it deals
+ * the candidate leaves of a scan to all wavefronts of the workgroup -- it publishes its
+ * 64 rays and the candidate mask in LDS; wavefront w tests candidates w, w + n, w + 2n, ...
+ * for all 64 rays -- and combines the shares afterwards: the nearest hit is the minimum
+ * of (distance, Scene index) over the shares, the shadow verdict their OR.  Both are
+ * independent of the order of the tests, hence exactly what the reference's in-order
+ * scans find (src/RayTracer.cpp:71-80, 727-729).  Same instructions as one wavefront
+ * would issue, on as many SIMDs as the workgroup has wavefronts. */
+#define RT_COOP_RAY0 0           /* 64 quads: ray origin, bound (nearest so far / distance to the light)   */
+#define RT_COOP_RAY1 64          /* 64 quads: ray direction, bits (nearest: Scene index so far; shadow: 1) or RT_COOP_IDLE */
+#define RT_COOP_CMD 128          /* 1 quad: bits {scan: 0 exit / 1 nearest / 2 shadow, first item of the round, mask lo, mask hi} */
+#define RT_COOP_PART 129         /* 32 quads per wavefront: its 64 lanes' {distance, Scene index} (nearest) or its ballot (shadow) */
+#define RT_COOP_IDLE 0x80000000u
+#ifndef RT_COOP_MIN_LEAVES
+#define RT_COOP_MIN_LEAVES 8     /* fewer candidate leaves than this: the leader tests them itself */
+#endif
 
-/* the value another lane holds (ds_bpermute: LDS crossbar, no memory) */
-__device__ __forceinline__ int lane_xor_i32(const int v, const int lane, const int mask) {
-    return __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, v);
-}
-
-/* Sliced tiles: pops up to 1 << log2 candidates off *mask (a wave-uniform bit set of
- * items base + bit); copy q gets the q-th of them, -1 if there were fewer. */
-__device__ __forceinline__ int deal_candidates(unsigned long long *mask, const int base, const Slicing<1> sl) {
-    int mine = -1;
-    for (int q = 0; q < (1 << sl.log2) && *mask != 0ull; ++q) {
-        const int src = __ffsll((long long)*mask) - 1;
-        *mask &= *mask - 1ull;
-        if (sl.copy == q) mine = base + src;
+/* A share of the candidate leaves of one round of a nearest-hit scan: candidates number
+ * share, share + n_shares, ... of leaf_mask (bit i = item base + i), tested for this
+ * wavefront's 64 rays; the code of the RT_KIND_SPHERE_LEAF case of nearest_hit_items(). */
+template <bool kStats>
+__device__ __forceinline__ void near_leaf_share(const float4 *lds, const float4 *items, const int base,
+                                                unsigned long long leaf_mask, const int share, const int n_shares,
+                                                const bool active, const V3 o, const V3 d, const V3 inv,
+                                                float *best_io, int *best_idx_io, Stats<kStats> &st) {
+    const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
+    float best = *best_io;
+    int best_idx = *best_idx_io;
+    int turn = 0;
+    while (leaf_mask != 0ull) {
+        const int item = base + (__ffsll((long long)leaf_mask) - 1);
+        leaf_mask &= leaf_mask - 1ull;
+        const bool mine = turn == share;
+        turn = turn + 1 == n_shares ? 0 : turn + 1;
+        if (!mine) continue;
+        const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
+        const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
+        const int n = (int)((bits >> 8) & 255u);
+        const float4 *g = lds + (bits >> 16);
+        const uint32_t *ids = lds_u32 + bits1;
+        st_wave(st, ST_WAVE_BOX_TESTS);
+        const bool lane_needs = active && box_needed(i0, i1, o, inv, best);
+        if (!wave_any(lane_needs)) continue;
+#pragma unroll 2
+        for (int i = 0; i < n; ++i) {
+            bool hit; float t;
+            st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+            sphere_distance(g[i], o, d, &hit, &t);
+            if (wave_any(hit)) {
+                const int member = (int)ids[i];
+                if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
+            }
+        }
     }
-    return mine;
+    *best_io = best;
+    *best_idx_io = best_idx;
 }
 
+/* the same for a shadow scan: returns blocked */
+template <bool kStats>
+__device__ __forceinline__ bool shadow_leaf_share(const float4 *lds, const float4 *items, const int base,
+                                                  unsigned long long leaf_mask, const int share, const int n_shares,
+                                                  bool blocked, const V3 o, const V3 d, const V3 inv,
+                                                  const float dist_to_light, Stats<kStats> &st) {
+    int turn = 0;
+    while (leaf_mask != 0ull) {
+        const int item = base + (__ffsll((long long)leaf_mask) - 1);
+        leaf_mask &= leaf_mask - 1ull;
+        const bool mine = turn == share;
+        turn = turn + 1 == n_shares ? 0 : turn + 1;
+        if (!mine) continue;
+        if (!wave_any(!blocked)) return true;
+        const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
+        const uint32_t bits = __float_as_uint(i0.w);
+        const int n = (int)((bits >> 8) & 255u);
+        const float4 *g = lds + (bits >> 16);
+        st_wave(st, ST_WAVE_BOX_TESTS);
+        const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
+        if (!wave_any(lane_needs)) continue;
+        st_wave(st, ST_SHADOW_LEAVES_UNION);
+#pragma unroll 2
+        for (int i = 0; i < n; ++i) {
+            bool hit; float t;
+            st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+            sphere_distance(g[i], o, d, &hit, &t);
+            blocked = blocked || (hit && t < dist_to_light);
+        }
+    }
+    return blocked;
+}
+
+/* First-pass tiles: does some ray of the wavefront need most of the candidate leaves of
+ * this round?  Every lane asks about four of them (lane, lane + 16, ... : four box tests
+ * for the wavefront); a ray that needs three out of four of the candidates it asked
+ * about makes the scan -- and with it the tile -- one for the second pass. */
+__device__ __forceinline__ bool some_ray_needs_most_leaves(const float4 *items, const int base, const int n_items,
+                                                           const unsigned long long leaf_mask, const bool active,
+                                                           const V3 o, const V3 inv, const float bound) {
+    const int lane = (int)(threadIdx.x & 63u);
+    int asked = 0, needed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int bit = (lane + 16 * j) & 63;
+        const bool candidate = active && ((leaf_mask >> bit) & 1ull) != 0ull;
+        const int probe = min(base + bit, n_items - 1);
+        const bool need = candidate && box_needed(items[2 * probe], items[2 * probe + 1], o, inv, bound);
+        asked += candidate ? 1 : 0;
+        needed += need ? 1 : 0;
+    }
+    return wave_any(asked >= 2 && 4 * needed >= 3 * asked);
+}
+
+/* kMode: 0 a first-pass tile that never defers itself, 2 one that may, 3 the leader of a second-pass workgroup */
 template <bool kStats, int kMode>
-__device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, const bool active,
+__device__ __forceinline__ void nearest_hit_items(const RtParams &p, float4 *lds, const bool active,
                                                   const V3 o, const V3 d, const bool have_origin_box,
                                                   const V3 origins_lo, const V3 origins_hi,
                                                   float *best_out, int *best_idx_out, Stats<kStats> &st,
-                                                  const Slicing<kMode> sl, bool *defer) {
-    constexpr bool kSliced = kMode == 1, kMayDefer = kMode == 2;
-    (void)kMayDefer;
+                                                  bool *defer) {
+    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3;
     float best = 65535.0f;
     int best_idx = -1;
     st_lane(st, ST_NEAREST_RAYS, active);
@@ -594,43 +672,34 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
          * result: the winner is the minimum of (distance, Scene index), which is what
          * the reference's in-order scan with a strict `<` finds. */
         /* which candidates are leaves of clustered runs: the items from p.near_first_leaf on */
-        if ((kSliced || kMayDefer) && p.n_clusters > 0) {
+        if ((kLeader || kMayDefer) && p.n_clusters > 0) {
             const int plain = min(max(p.near_first_leaf - base, 0), 64);
-            unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
-            if constexpr (!kSliced) {
-                if (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves) {
-                    /* many candidate leaves: how DENSE is the (ray, leaf) matrix?  Lane i asks whether
-                     * its own ray needs leaf i -- the diagonal, one box test for the wavefront */
-                    const bool sampled = active && ((leaf_mask >> lane) & 1ull) != 0ull;
-                    const int probe = min(base + lane, p.n_near_items - 1);
-                    const bool needed = sampled && box_needed(items[2 * probe], items[2 * probe + 1], o, inv, best);
-                    const int n_sampled = __popcll(__builtin_amdgcn_ballot_w64(sampled));
-                    if (n_sampled >= 4 && 2 * __popcll(__builtin_amdgcn_ballot_w64(needed)) >= n_sampled) { *defer = true; mask = 0ull; base = p.n_near_items; }
+            const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
+            if constexpr (kMayDefer) {
+                if (p.defer_leaves < 0 ? leaf_mask != 0ull      /* < 0: every tile with a candidate leaf (tests) */
+                                       : (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves &&
+                                          some_ray_needs_most_leaves(items, base, p.n_near_items, leaf_mask, active, o, inv, best))) {
+                    *defer = true; mask = 0ull; base = p.n_near_items;      /* ends the scan */
                 }
-            } else {
+            } else if (__popcll(leaf_mask) >= RT_COOP_MIN_LEAVES) {
+                /* the workgroup shares these leaves (DEFERRED tiles above) */
                 mask &= ~leaf_mask;
                 if (lane >= plain) key = 0xFFFFFFFFu;               /* not the ordered loop's business */
-                while (leaf_mask != 0ull) {
-                    const int mine = deal_candidates(&leaf_mask, base, sl);
-                    const int item = mine >= 0 ? mine : base;
-                    const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
-                    const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
-                    const int n = (int)((bits >> 8) & 255u);
-                    const float4 *g = lds + (bits >> 16);
-                    const uint32_t *ids = lds_u32 + bits1;
-                    st_wave(st, ST_WAVE_BOX_TESTS);
-                    const bool lane_needs = mine >= 0 && active && box_needed(i0, i1, o, inv, best);
-                    for (int i = 0; wave_any(lane_needs && i < n); ++i) {
-                        const int ic = min(i, n - 1);
-                        bool hit; float t;
-                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs && i < n);
-                        sphere_distance(g[ic], o, d, &hit, &t);
-                        hit = hit && lane_needs && i < n;
-                        if (wave_any(hit)) {
-                            const int member = (int)ids[ic];
-                            if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
-                        }
-                    }
+                float4 *coop = lds + p.coop_off;
+                const int n_shares = (int)(blockDim.x >> 6);
+                coop[RT_COOP_RAY0 + lane] = make_float4(o.x, o.y, o.z, best);
+                coop[RT_COOP_RAY1 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(active ? (uint32_t)best_idx : RT_COOP_IDLE));
+                if (lane == 0)
+                    coop[RT_COOP_CMD] = make_float4(__uint_as_float(1u), __uint_as_float((uint32_t)base),
+                                                    __uint_as_float((uint32_t)leaf_mask), __uint_as_float((uint32_t)(leaf_mask >> 32)));
+                __syncthreads();
+                near_leaf_share<kStats>(lds, items, base, leaf_mask, 0, n_shares, active, o, d, inv, &best, &best_idx, st);
+                __syncthreads();
+                const float2 *part = reinterpret_cast<const float2 *>(coop + RT_COOP_PART);
+                for (int w = 1; w < n_shares; ++w) {
+                    const float2 other = part[w * 64 + lane];
+                    const int oi = __float_as_int(other.y);
+                    if (oi >= 0 && (best_idx < 0 || nearer(other.x, oi, best, best_idx))) { best = other.x; best_idx = oi; }
                 }
             }
         }
@@ -719,15 +788,6 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             }
         }
     }
-    if constexpr (kSliced) {
-        /* the copies of a ray tested different leaves: the minimum of (distance, Scene index) */
-        for (int k = 0; k < sl.log2; ++k) {
-            const int stride = (64 >> sl.log2) << k;
-            const float ot = __int_as_float(lane_xor_i32(__float_as_int(best), lane, stride));
-            const int oi = lane_xor_i32(best_idx, lane, stride);
-            if (oi >= 0 && (best_idx < 0 || nearer(ot, oi, best, best_idx))) { best = ot; best_idx = oi; }
-        }
-    }
     *best_out = best;
     *best_idx_out = active ? best_idx : -1;
 }
@@ -758,23 +818,12 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
     *centre = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
 }
 
-/* OR of `blocked` over the copies of each ray of a sliced tile (all 64 lanes active) */
-__device__ __forceinline__ bool or_over_copies(const bool blocked, const int log2) {
-    unsigned long long m = __builtin_amdgcn_ballot_w64(blocked);
-    for (int k = 0; k < log2; ++k) {
-        const int stride = (64 >> log2) << k;
-        m |= (m >> stride) | (m << (64 - stride));        /* rotations: every copy sees every other */
-    }
-    return ((m >> (threadIdx.x & 63u)) & 1ull) != 0ull;
-}
-
 template <bool kStats, int kMode>
-__device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, const bool active,
+__device__ __forceinline__ bool in_shade(const RtParams &p, float4 *lds, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
                                          const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
-                                         const Slicing<kMode> sl, bool *defer) {
-    constexpr bool kSliced = kMode == 1, kMayDefer = kMode == 2;
-    (void)kMayDefer;
+                                         bool *defer) {
+    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3;
     bool blocked = !active;
     int stat_my_leaves = 0;
     if (p.n_shadow_items == 0) return false;
@@ -822,37 +871,32 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, c
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
-        if ((kSliced || kMayDefer) && p.n_clusters > 0) {
+        if ((kLeader || kMayDefer) && p.n_clusters > 0) {
             const int plain = min(max(p.shadow_first_leaf - base, 0), 64);
-            unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
-            if constexpr (!kSliced) {
-                if (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves) {        /* as in nearest_hit_items() */
-                    const bool sampled = active && ((leaf_mask >> lane) & 1ull) != 0ull;
-                    const int probe = min(base + lane, p.n_shadow_items - 1);
-                    const bool needed = sampled && box_needed(items[2 * probe], items[2 * probe + 1], o, inv, dist_to_light);
-                    const int n_sampled = __popcll(__builtin_amdgcn_ballot_w64(sampled));
-                    if (n_sampled >= 4 && 2 * __popcll(__builtin_amdgcn_ballot_w64(needed)) >= n_sampled) { *defer = true; mask = 0ull; base = p.n_shadow_items; }
+            const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
+            if constexpr (kMayDefer) {
+                if (p.defer_leaves < 0 ? leaf_mask != 0ull
+                                       : (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves &&
+                                          some_ray_needs_most_leaves(items, base, p.n_shadow_items, leaf_mask, !blocked, o, inv, dist_to_light))) {
+                    *defer = true; mask = 0ull; base = p.n_shadow_items;    /* ends the scan */
                 }
-            } else {
+            } else if (__popcll(leaf_mask) >= RT_COOP_MIN_LEAVES) {
+                /* the workgroup shares these leaves (DEFERRED tiles, above nearest_hit_items()) */
                 mask &= ~leaf_mask;
-                while (leaf_mask != 0ull) {
-                    if (!wave_any(!blocked)) return true;
-                    const int mine = deal_candidates(&leaf_mask, base, sl);
-                    const int item = mine >= 0 ? mine : base;
-                    const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
-                    const uint32_t bits = __float_as_uint(i0.w);
-                    const int n = (int)((bits >> 8) & 255u);
-                    const float4 *g = lds + (bits >> 16);
-                    st_wave(st, ST_WAVE_BOX_TESTS);
-                    const bool lane_needs = mine >= 0 && !blocked && box_needed(i0, i1, o, inv, dist_to_light);
-                    bool mine_blocked = false;
-                    for (int i = 0; wave_any(lane_needs && !mine_blocked && i < n); ++i) {
-                        bool hit; float t;
-                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs && i < n);
-                        sphere_distance(g[min(i, n - 1)], o, d, &hit, &t);
-                        mine_blocked = mine_blocked || (lane_needs && i < n && hit && t < dist_to_light);
-                    }
-                    blocked = or_over_copies(blocked || mine_blocked, sl.log2);
+                float4 *coop = lds + p.coop_off;
+                const int n_shares = (int)(blockDim.x >> 6);
+                coop[RT_COOP_RAY0 + lane] = make_float4(o.x, o.y, o.z, dist_to_light);
+                coop[RT_COOP_RAY1 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(blocked ? RT_COOP_IDLE : 1u));
+                if (lane == 0)
+                    coop[RT_COOP_CMD] = make_float4(__uint_as_float(2u), __uint_as_float((uint32_t)base),
+                                                    __uint_as_float((uint32_t)leaf_mask), __uint_as_float((uint32_t)(leaf_mask >> 32)));
+                __syncthreads();
+                blocked = shadow_leaf_share<kStats>(lds, items, base, leaf_mask, 0, n_shares, blocked, o, d, inv, dist_to_light, st);
+                __syncthreads();
+                const uint32_t *part = reinterpret_cast<const uint32_t *>(coop + RT_COOP_PART);
+                for (int w = 1; w < n_shares; ++w) {
+                    const unsigned long long theirs = (unsigned long long)part[w * 128] | ((unsigned long long)part[w * 128 + 1] << 32);
+                    blocked = blocked || ((theirs >> lane) & 1ull) != 0ull;
                 }
             }
         }
@@ -979,30 +1023,22 @@ __device__ __forceinline__ V3 entry_colour(const RtParams &p, const float4 *lds,
  * buffer below 2^32 entries), so no per-lane address lives across the scans. */
 __device__ __forceinline__ size_t hbm_stack_entry(const RtParams &p, const int level) {
     const unsigned int row = (unsigned int)here((int)blockIdx.x) * (unsigned int)(p.max_depth + 1) + (unsigned int)level;
-    return (size_t)(row * blockDim.x + threadIdx.x);
+    return (size_t)(row * (unsigned int)here(p.stack_stride) + threadIdx.x);
 }
 
 /* One wavefront tile: camera rays, the bounce loop, the unwind, the store.  Returns true
- * if the tile deferred itself (nothing stored).  kSliced: a sub-tile of a deferred tile,
- * 64 >> slice_log2 pixels, every ray in 1 << slice_log2 lanes (Slicing above); `sub` says
- * which part of the 64-pixel tile. */
+ * if the tile deferred itself (kMode 2; nothing is stored then). */
 template <bool kStats, int kMode>
 __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, float *__restrict__ out,
                                             float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
-                                            Stats<kStats> &st, const int wave, const int sub,
-                                            const int my_xcc, const int steal) {
-    constexpr bool kSliced = kMode == 1, kMayDefer = kMode == 2;
-    (void)kMayDefer;
+                                            Stats<kStats> &st, const int wave, const int my_xcc, const int steal) {
+    constexpr bool kMayDefer = kMode == 2;
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
     const int lane = threadIdx.x & 63;
     unsigned long long t_start = 0ull, t_start_real = 0ull;
     const int tile_row = wave / p.tiles_x;                  /* tile number, row-major */
     const int tile_col = wave - tile_row * p.tiles_x;
-    Slicing<kMode> sl;
-    if constexpr (kSliced) { sl.log2 = p.slice_log2; sl.copy = lane >> (6 - p.slice_log2); }
     bool defer = false;
-    /* pixel of the tile this lane works on: all 64 of them, or the sub-tile's share */
-#define RT_TILE_PIXEL() (kSliced ? ((here(sub) << (6 - here(p.slice_log2))) + (lane & ((64 >> here(p.slice_log2)) - 1))) : lane)
     unsigned int tile_sphere0 = 0u, tile_box0 = 0u;
     if constexpr (kStats) {
         tile_sphere0 = st.c[ST_WAVE_SPHERE_TESTS]; tile_box0 = st.c[ST_WAVE_BOX_TESTS];
@@ -1013,9 +1049,8 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
     /* pixel of this lane: wavefront tiles are tile_x columns by tile_z rows;
      * consecutive lanes walk z, the contiguous axis of pixels[x][z] */
     const int tzl_a = here(p.tile_z_log2);
-    const int pix_a = RT_TILE_PIXEL();
-    const int x = p.x0 + tile_col * (64 >> tzl_a) + (pix_a >> tzl_a);
-    const int z = (tile_row << tzl_a) + (pix_a & ((1 << tzl_a) - 1));
+    const int x = p.x0 + tile_col * (64 >> tzl_a) + (lane >> tzl_a);
+    const int z = (tile_row << tzl_a) + (lane & ((1 << tzl_a) - 1));
     const bool inside = (x < p.x1) && (z < p.H);
 
     /* Camera::createEyeRay, src/Camera.cpp:71-84, with dx = (float)x / W,
@@ -1052,7 +1087,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
         const unsigned long long t_scan = st_clock<kStats>();
-        nearest_hit_items<kStats, kMode>(p, lds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, sl, &defer);   /* whole wavefront, converged */
+        nearest_hit_items<kStats, kMode>(p, lds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, &defer);   /* whole wavefront, converged */
         if (kMayDefer && defer) alive = false;                /* deferred: nothing more to trace, nothing to store */
         st_cycles(st, ST_CYCLES_NEAREST, t_scan);
         const unsigned long long t_winner = st_clock<kStats>();
@@ -1128,7 +1163,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
-                const bool blocked = in_shade<kStats, kMode>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, sl, &defer);
+                const bool blocked = in_shade<kStats, kMode>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
                 if (kMayDefer && defer) { shade = false; alive = false; }
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
@@ -1182,7 +1217,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
                 float4 e;
                 e.x = C.x; e.y = C.y; e.z = C.z;
                 e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
-                if (level < p.stack_lds_levels) lds[here(p.image_quads) + level * blockDim.x + threadIdx.x] = e;
+                if (level < p.stack_lds_levels) lds[here(p.image_quads) + level * here(p.stack_stride) + threadIdx.x] = e;
                 else                            bounce_stack[hbm_stack_entry(p, level)] = e;
                 top = level + 1;
                 o = P;
@@ -1200,7 +1235,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
     for (int k = levels - 1; k >= 0; --k) {
         if (k < top) {
             float4 e;
-            if (k < p.stack_lds_levels) e = lds[here(p.image_quads) + k * blockDim.x + threadIdx.x];
+            if (k < p.stack_lds_levels) e = lds[here(p.image_quads) + k * here(p.stack_stride) + threadIdx.x];
             else                        e = bounce_stack[hbm_stack_entry(p, k)];
             const uint32_t bits = __float_as_uint(e.w);
             const uint32_t info = lds_u32[p.objinfo_off * 4 + (bits & 0xFFFFu)];
@@ -1214,13 +1249,11 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
     }
 
     bool stores = inside;
-    if constexpr (kSliced) stores = inside && sl.copy == 0;   /* one copy of each ray stores */
-    else if constexpr (kMayDefer) stores = inside && !defer;
+    if constexpr (kMayDefer) stores = inside && !defer;
     if (stores) {
         const int tzl_b = here(p.tile_z_log2);
-        const int pix_b = RT_TILE_PIXEL();
-        const int sx = here(tile_col) * (64 >> tzl_b) + (pix_b >> tzl_b);   /* x - x0 */
-        const int sz = (here(tile_row) << tzl_b) + (pix_b & ((1 << tzl_b) - 1));
+        const int sx = here(tile_col) * (64 >> tzl_b) + (lane >> tzl_b);   /* x - x0 */
+        const int sz = (here(tile_row) << tzl_b) + (lane & ((1 << tzl_b) - 1));
         float *dst = out + ((size_t)sx * (size_t)p.H + (size_t)sz) * 3;
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
     }
@@ -1230,7 +1263,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
          * (the totals are added up once per wavefront, after its last tile) */
         {
             unsigned long long *rec = stats_out + ST_COUNT + (size_t)wave * RT_TILE_STATS;
-            if (lane == 0 && (!kSliced || sub == 0)) {               /* a sliced tile reports its first sub-tile */
+            if (lane == 0) {
                 rec[0] = __builtin_amdgcn_s_memtime() - t_start;
                 rec[4] = t_start_real;                               /* 100 MHz constant clock */
                 rec[5] = __builtin_amdgcn_s_memrealtime();
@@ -1242,7 +1275,6 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
         }
     }
     return defer;
-#undef RT_TILE_PIXEL
 }
 
 template <bool kStats, bool kSecondPass, bool kMayDefer>
@@ -1294,16 +1326,53 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int lane = threadIdx.x & 63;
     const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
   if constexpr (kSecondPass) {
-    const int n_sub = (int)defer_list[0] << p.slice_log2;
-    unsigned int *const head = tile_counter + RT_TILE_QUEUES * RT_QUEUE_STRIDE;
-    int next_pop = 0;
-    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-    for (;;) {
-        const int pop = __builtin_amdgcn_readfirstlane(next_pop);
-        if (pop >= n_sub) break;
+    /* second pass: the workgroup renders one deferred tile at a time (DEFERRED tiles, above) */
+    float4 *coop = lds + p.coop_off;
+    const int my_wave = (int)(threadIdx.x >> 6), n_waves = (int)(blockDim.x >> 6);
+    if (my_wave == 0) {
+        const int n_deferred = (int)defer_list[0];
+        unsigned int *const head = tile_counter + RT_TILE_QUEUES * RT_QUEUE_STRIDE;
+        int next_pop = 0;
         if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-        const int tile = (int)defer_list[1 + (pop >> p.slice_log2)];
-        (void)render_tile<kStats, 1>(p, lds, out, bounce_stack, stats_out, st, tile, pop & ((1 << p.slice_log2) - 1), my_xcc, 0);
+        for (;;) {
+            const int pop = __builtin_amdgcn_readfirstlane(next_pop);
+            if (pop >= n_deferred) break;
+            if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+            (void)render_tile<kStats, 3>(p, lds, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
+        }
+        if (lane == 0) coop[RT_COOP_CMD] = make_float4(__uint_as_float(0u), 0.0f, 0.0f, 0.0f);     /* exit */
+        __syncthreads();
+    } else {
+        /* a helper: wait for the leader's scans and test this wavefront's share of their leaves */
+        for (;;) {
+            __syncthreads();
+            const float4 cmd = coop[RT_COOP_CMD];
+            const uint32_t scan = __float_as_uint(cmd.x);
+            if (scan == 0u) break;
+            const int base = (int)__float_as_uint(cmd.y);
+            const unsigned long long leaf_mask = (unsigned long long)__float_as_uint(cmd.z) | ((unsigned long long)__float_as_uint(cmd.w) << 32);
+            const float4 r0 = coop[RT_COOP_RAY0 + lane], r1 = coop[RT_COOP_RAY1 + lane];
+            const V3 o = xyz(r0), d = xyz(r1);
+            const V3 inv = approx_inverse(d);
+            const uint32_t state = __float_as_uint(r1.w);
+            if (scan == 1u) {
+                float best = r0.w;
+                int best_idx = state == RT_COOP_IDLE ? -1 : (int)state;
+                near_leaf_share<kStats>(lds, lds + p.near_items_off, base, leaf_mask, my_wave, n_waves, state != RT_COOP_IDLE,
+                                        o, d, inv, &best, &best_idx, st);
+                reinterpret_cast<float2 *>(coop + RT_COOP_PART)[my_wave * 64 + lane] = make_float2(best, __int_as_float(best_idx));
+            } else {
+                const bool blocked = shadow_leaf_share<kStats>(lds, lds + p.shadow_items_off, base, leaf_mask, my_wave, n_waves,
+                                                               state == RT_COOP_IDLE, o, d, inv, r0.w, st);
+                const unsigned long long verdict = __builtin_amdgcn_ballot_w64(blocked && state != RT_COOP_IDLE);
+                if (lane == 0) {
+                    uint32_t *part = reinterpret_cast<uint32_t *>(coop + RT_COOP_PART);
+                    part[my_wave * 128] = (uint32_t)verdict;
+                    part[my_wave * 128 + 1] = (uint32_t)(verdict >> 32);
+                }
+            }
+            __syncthreads();
+        }
     }
   } else {
     const int macro_rows = (p.tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
@@ -1323,12 +1392,13 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
     const int queued_row = macro / p.tiles_x;
     const int tile_col = macro - queued_row * p.tiles_x;
-    const int shifted_row = queued_row + p.first_macro_row;                         /* first_macro_row < macro_rows */
-    const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : shifted_row;
+    /* from first_macro_row (< macro_rows) upwards, or (rows_downwards) downwards; both wrap around */
+    const int shifted_row = p.rows_downwards ? p.first_macro_row - queued_row : p.first_macro_row + queued_row;
+    const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : (shifted_row < 0 ? shifted_row + macro_rows : shifted_row);
     const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
     if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
-    if (render_tile<kStats, kMayDefer ? 2 : 0>(p, lds, out, bounce_stack, stats_out, st, wave, 0, my_xcc, steal)) {
+    if (render_tile<kStats, kMayDefer ? 2 : 0>(p, lds, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
         /* the tile deferred itself: the second pass renders it */
         if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
     }
@@ -1354,17 +1424,19 @@ rt_render_kernel(const RtParams p, const float4 *__restrict__ image, float *__re
 }
 
 /* the first pass for scenes whose tiles may defer themselves (clustered sphere runs) ... */
-extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
+#ifndef RT_WAVES_PER_SIMD_DEFERRING
+#define RT_WAVES_PER_SIMD_DEFERRING 6
+#endif
+extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_DEFERRING)
 rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
                            unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                            unsigned int *__restrict__ defer_list) {
     render_body<false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
-/* ... and the second pass: the deferred tiles, sliced (its own kernel: the per-lane leaf records
- * need more registers than the seven-wavefront budget of the first pass holds) */
-extern "C" __global__ void __launch_bounds__(256, 5)
-rt_render_kernel_sliced(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+/* ... and the second pass: the deferred tiles, one per workgroup (of up to 8 wavefronts) at a time */
+extern "C" __global__ void __launch_bounds__(512)
+rt_render_kernel_second(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
                         unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                         unsigned int *__restrict__ defer_list) {
     render_body<false, true, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
@@ -1379,7 +1451,7 @@ rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, float
 }
 
 extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_sliced_stats(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+rt_render_kernel_second_stats(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
                               unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                               unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
     render_body<true, true, false>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);

@@ -108,11 +108,9 @@
 #define RT_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)   /* s_getreg_b32 HW_REG_XCC_ID, bits [3:0] */
 
 #ifndef RT_DEFER_LEAVES
-#define RT_DEFER_LEAVES 0            /* automatic: a scan with this many candidate leaves, half of them needed by the sampled rays, defers its tile */
+#define RT_DEFER_LEAVES 32           /* automatic: a scan with this many candidate leaves, most of them needed by some ray, defers its tile */
 #endif
-#ifndef RT_DEFER_SLICES
-#define RT_DEFER_SLICES 8            /* copies of each ray in a deferred (sliced) tile */
-#endif
+#define RT_COOP_QUADS(waves) (129 + 32 * (waves))   /* LDS of the second pass's workgroups: 64 + 64 ray quads, a command, 32 per wavefront */
 
 #define RT_NEAR_CULL_MIN_ITEMS 8     /* below this many items the nearest scan skips the bundle cull */
 #define RT_SHADOW_CULL_MIN_ITEMS 8   /* below this many shadow items the wavefront skips the bundle-box cull */
@@ -142,14 +140,17 @@ typedef struct RtParams {
     int32_t tiles_z;                     /* wavefront tiles along z */
     int32_t tiles_x;                     /* wavefront tiles along x */
     int32_t n_tiles;                     /* total wavefront tiles   */
+    int32_t stack_stride;                /* threads that keep a bounce stack per workgroup: all of them, or 64 (the leader) in the second pass */
     int32_t stack_lds_levels;            /* bounce levels below this keep their stack entries in LDS (behind the tables), the others in HBM */
-    int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around */
-    /* Deferred tiles.  pass 0 renders every tile with one pixel per lane, except that a tile one of
-     * whose scans is left with >= defer_leaves candidate leaves by its bundle cull (0: never) abandons
-     * itself and appends its number to the defer list {count, tile, tile, ...}.  pass 1 (a second
-     * launch on the same stream) renders the listed tiles SLICED: 1 << slice_log2 sub-tiles of
-     * 64 >> slice_log2 pixels, each ray in 1 << slice_log2 lanes that share the candidate leaves. */
-    int32_t defer_leaves, pass, slice_log2;
+    int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around ... */
+    int32_t rows_downwards;              /* ... upwards (0) or downwards (1)                           */
+    /* Deferred tiles (rt_kernel.hip, "DEFERRED tiles").  The first pass renders every tile, except that a
+     * tile one of whose scans is left with >= defer_leaves candidate leaves by its bundle cull (0: never),
+     * most of them needed by some ray, abandons itself and appends its number to the defer list
+     * {count, tile, tile, ...}.  The second pass (another launch on the same stream) renders the listed
+     * tiles one per WORKGROUP: wavefront 0 leads, all wavefronts share the candidate leaves of its scans
+     * through the LDS area at quad coop_off (behind the tables and the bounce stack). */
+    int32_t defer_leaves, coop_off;
     int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
 } RtParams;
 
