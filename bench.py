@@ -60,6 +60,8 @@ WORKLOADS = {
     "grid32-noshadow":  ("grid32-noshadow", 4096, 4096, 4, "configs[2] variant: shadow scan range [0,0) as in the survey fixtures"),
     "grid16d8":         ("grid16",          4096, 4096, 8, "configs[4]: 256-sphere grid, 4096x4096, depth 8 (shadow scan on)"),
     "builtin8k":        ("builtin",         8192, 8192, 4, "configs[3]: 8192x8192 tiled one strip per GPU"),
+    "twomirrors":       ("twomirrors",      4096, 4096, 50, "not a BASELINE config: the reference's SCENE 2 (3 920 objects, facing mirrors, "
+                                                             "src/Scene.cpp:23-206), MAX_RECURSION_LEVEL 50; tables of 119 KB read from global memory"),
 }
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

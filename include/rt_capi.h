@@ -35,7 +35,7 @@ enum {
     RT_ERR_INVALID = 1,      /* bad argument / malformed description        */
     RT_ERR_NO_DEVICE = 2,    /* no usable HIP device                        */
     RT_ERR_HIP = 3,          /* a HIP runtime call failed                   */
-    RT_ERR_CAPACITY = 4,     /* scene + bounce stack do not fit in LDS      */
+    RT_ERR_CAPACITY = 4,     /* more than 4 096 objects, a bounce stack beyond 8 GB, or an LDS option that does not fit */
     RT_ERR_RCCL = 5          /* an RCCL call failed (rt_render_multi)       */
 };
 
@@ -176,6 +176,9 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *   "tile_z"        wavefront tile height, 1,2,4,...,64 (width = 64 / height)
  *   "block_threads" 0 = auto, else 64, 128, 192 or 256
  *   "stack"         bounce stack: 0 auto, 1 LDS, 2 HBM
+ *   "tables"        where the kernel reads the scene tables: 1 = LDS (staged once per
+ *                   workgroup; at most 160 KiB), 2 = global memory through the L2 (any
+ *                   size), 0 = automatic (LDS up to 80 KiB)
  *   "grid_mult"     persistent grid = occupancy x CUs x this; 0 = no persistence
  *   "first_row"     where the tile queues start, thousandths of the image
  *                   height (rows wrap around); -1 = automatic

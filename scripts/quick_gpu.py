@@ -23,3 +23,19 @@ for name, S, d in cases:
     tm = r.timing(); li = r.launch_info()
     ms = tm.sum_kernel_ms / tm.launches
     print(f"{name:16s} {S}x{S} d{d}: {ms:9.3f} ms  {S*S/ms/1e3:9.1f} Mrays/s  block {li.block_threads} lds {li.lds_bytes} tile {li.tile_x}x{li.tile_z} grid {li.grid_blocks}", flush=True)
+# the reference's SCENE 2 (two mirrors, 3 920 objects) at 1024^2, depth 50: tables in LDS vs global memory
+if "only" not in opts or "twomirrors" in opts["only"]:
+    for tables in (1, 2):
+        r = Renderer(HostScene.named("twomirrors"))
+        r.set_option("tables", tables)
+        S, d = 1024, 50
+        buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.cuda.current_stream().cuda_stream
+        r.render_device(S, S, d, 0, S, buf.data_ptr(), st); torch.cuda.synchronize()
+        r.reset_timing()
+        for _ in range(2):
+            r.render_device(S, S, d, 0, S, buf.data_ptr(), st)
+        torch.cuda.synchronize()
+        tm = r.timing(); li = r.launch_info()
+        ms = tm.sum_kernel_ms / tm.launches
+        print(f"twomirrors tables={tables} {S}x{S} d{d}: {ms:9.3f} ms  {S*S/ms/1e3:9.1f} Mrays/s  block {li.block_threads} lds {li.lds_bytes} scene lds {li.scene_lds_bytes} grid {li.grid_blocks}", flush=True)

@@ -533,7 +533,7 @@ def test_inside_a_clustered_sphere_field(oracle):
     assert_same(r.render(64, 64, 4), want, "inside a clustered field, plain scan")
 
 
-@pytest.mark.parametrize("name,W,H,depth", [("builtin", 150, 130, 4), ("grid16", 96, 96, 8), ("grid32", 64, 96, 4)])
+@pytest.mark.parametrize("name,W,H,depth", [("builtin", 150, 130, 4), ("grid16", 96, 96, 8), ("grid32", 64, 96, 4), ("twomirrors", 32, 32, 5)])
 def test_plain_scan_option(oracle, name, W, H, depth):
     """rt_set_option("cull", 0): no bundle culls, no nearest-first exit, no sphere clustering, no
     axis-aligned route -- the in-order scans of src/RayTracer.cpp:50-89, 709-739 as they stand."""
@@ -697,3 +697,80 @@ def test_second_pass_inside_a_clustered_sphere_field(oracle):
     r.set_option("defer", 65)
     assert_same(r.render(64, 64, 4), want, "inside a clustered field, deferred")
     assert r.launch_info().deferred_tiles > 0
+
+
+# ------------------------------------------------ round 2: scenes larger than LDS (tables in global memory)
+def _mixed_scene(scene, n_objects, seed=3):
+    """Alternating spheres and finite planes (no runs: nothing clusters, every object is a plain
+    item with its full record) up to the reference's Scene capacity (MAX_OBJECT_COUNT 4000, of which
+    addObject fills 3 999, src/Scene.h:8, src/Scene.cpp:470-479)."""
+    rng = np.random.RandomState(seed)
+    f = lambda x: float(np.float32(x))
+    i = scene.add_sphere((3.0, 5.0, 9.0), 0.15)
+    scene.set_light(i)
+    for k in range(n_objects - 1):
+        c = (f(rng.uniform(-9, 9)), f(rng.uniform(3, 40)), f(rng.uniform(0, 7)))
+        if k % 2 == 0:
+            i = scene.add_sphere(c, f(rng.uniform(0.05, 0.35)))
+        elif k % 4 == 1:
+            i = scene.add_finite_plane_axes(c, tuple(f(v) for v in rng.uniform(-1, 1, 3)), tuple(f(v) for v in rng.uniform(-1, 1, 3)),
+                                            f(rng.uniform(0.2, 0.8)), f(rng.uniform(0.2, 0.8)))
+        else:
+            i = scene.add_finite_plane_corners(c, (c[0], c[1], f(c[2] + 0.5)), (f(c[0] + 0.5), c[1], c[2]))   # axis-aligned
+        scene.set_color(i, [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0)][k % 4])
+        if k % 5 == 0:
+            scene.set_reflective(i, 0.5)
+    scene.set_object_indices(0, 1)
+    scene.camera_two_mirrors()
+    return scene
+
+
+def test_3999_object_mixed_scene(oracle):
+    host = _mixed_scene(HostScene.empty(), 3999)
+    assert host.object_count == 3999
+    r = Renderer(host)
+    want = _mixed_scene(oracle.OracleScene(), 3999).render(48, 40, 3)
+    assert_same(r.render(48, 40, 3), want, "3 999 mixed objects")
+    li = r.launch_info()
+    assert li.scene_lds_bytes == 0                      # tables of ~500 KB: read from global memory
+    r.set_option("cull", 0)
+    assert_same(r.render(48, 40, 3, 5, 29), want[5:29], "3 999 mixed objects, plain scan, strip")
+
+
+@pytest.mark.parametrize("tables", [1, 2])
+@pytest.mark.parametrize("name,W,H,depth", [("builtin", 100, 90, 4), ("grid16", 64, 64, 8), ("twomirrors", 32, 32, 6)])
+def test_tables_in_lds_or_global_memory(oracle, name, W, H, depth, tables):
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    r.set_option("tables", tables)
+    assert_same(r.render(W, H, depth), want, f"{name}, tables={tables}")
+    assert (r.launch_info().scene_lds_bytes == 0) == (tables == 2)
+
+
+def test_two_mirrors_512_depth_50(oracle):
+    """The reference's SCENE 2 (3 920 objects, facing mirrors) at 512 x 512, MAX_RECURSION_LEVEL 50,
+    every pixel; then the same with the plain scans (no clusters: 313 KB of tables, global memory)."""
+    import ctypes as C
+    W = H = 512
+    scene = oracle.OracleScene.two_mirrors()
+    want = np.empty((W, H, 3), np.float32)
+    starts = (C.c_int * (W // 8))(*range(0, W, 8))
+    sec = C.c_double()
+    assert oracle.LIB.orc_render_static_partition(scene.h, C.byref(scene.cam), W, H, 50, starts, W // 8, 8, 8, None,
+                                                  want.ctypes.data, C.byref(sec)) == 0
+    r = Renderer(HostScene.two_mirrors())
+    assert_same(r.render(W, H, 50), want, "two mirrors 512^2 d50")
+    r.set_option("cull", 0)
+    assert_same(r.render(W, H, 50, 200, 264), want[200:264], "two mirrors 512^2 d50, plain scan, columns 200:264")
+    assert r.launch_info().scene_lds_bytes == 0
+
+
+def test_tables_option_that_does_not_fit_is_refused(oracle):
+    from tilecoderaytracer_amd import RtError, capi
+    r = Renderer(_mixed_scene(HostScene.empty(), 3000))
+    r.set_option("tables", 1)
+    with pytest.raises(RtError) as e:
+        r.render(8, 8, 2)
+    assert e.value.code == capi.RT_ERR_CAPACITY
+    r.set_option("tables", 0)
+    assert r.render(8, 8, 2).shape == (8, 8, 3)

@@ -25,6 +25,12 @@ extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__re
                                             float4 *__restrict__ bounce_stack,
                                             unsigned int *__restrict__ defer_list);
 
+extern "C" __global__ void rt_render_kernel_large(const RtParams p, const float4 *__restrict__ image,
+                                                  float *__restrict__ out,
+                                                  unsigned int *__restrict__ tile_counter,
+                                                  float4 *__restrict__ bounce_stack,
+                                                  unsigned int *__restrict__ defer_list);
+
 extern "C" __global__ void rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image,
                                                       float *__restrict__ out,
                                                       unsigned int *__restrict__ tile_counter,
@@ -98,6 +104,7 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
+    int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int second_block_opt = 0;     /* threads per workgroup of the second pass: 0 = as the first pass, else 64..512 */
     int defer_opt = -1;           /* a scan with this many candidate leaves (most of them needed by some ray) defers its tile
                                      to the second, workgroup-cooperative pass; -1 = automatic (RT_DEFER_LEAVES when the
@@ -528,8 +535,6 @@ int pack_scene(rt_scene *s) {
     b.n_clusters = n_clusters;
     b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
     for (int c = 0; c < 3; ++c) b.null_color[c] = s->null_color[c];
-    if ((size_t)b.image_quads * 16 > RT_MAX_LDS_BYTES)
-        return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
     s->image.swap(image);
     s->base = b;
     s->n_clusters = n_clusters;
@@ -653,9 +658,15 @@ int horizon_start(const rt_scene *s, const rt_camera_desc *cam) {
  * tables while RT_STACK_LDS_SHARE workgroups per CU still fit in the 160 KiB
  * (nearly every reflection chain uses the first levels, few the deep ones); the
  * rest lives in HBM.  Option "stack": 1 = all of it in LDS, 2 = all in HBM. */
-int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, int *stack_lds_levels) {
-    const size_t scene_bytes = (size_t)s->base.image_quads * 16;
-    if (scene_bytes > RT_MAX_LDS_BYTES) return fail(RT_ERR_CAPACITY, "scene tables do not fit in LDS (160 KiB)");
+int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, int *stack_lds_levels, bool *global_tables) {
+    /* Tables in LDS (staged once per workgroup), or -- large scenes -- left in global memory and read
+     * through the L2 (rt_render_kernel_large): automatic beyond RT_LDS_TABLE_BYTES, where LDS would hold
+     * fewer than two workgroups per CU; beyond 160 KiB it is the only way.  Option "tables". */
+    size_t scene_bytes = (size_t)s->base.image_quads * 16;
+    *global_tables = s->tables_opt == 2 || (s->tables_opt == 0 && scene_bytes > RT_LDS_TABLE_BYTES);
+    if (!*global_tables && scene_bytes > RT_MAX_LDS_BYTES)
+        return fail(RT_ERR_CAPACITY, "option tables=1: the scene tables do not fit in LDS (160 KiB)");
+    if (*global_tables) scene_bytes = 0;
     *block = s->block_threads_opt ? s->block_threads_opt : 256;
     const double per_level = (double)RT_STACK_ENTRY_BYTES * (double)*block;
     const double levels = (double)max_depth + 1.0;
@@ -671,6 +682,7 @@ int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, i
     }
     *stack_lds_levels = (int)in_lds;
     *lds_bytes = (int)((double)scene_bytes + in_lds * per_level);
+    if (*lds_bytes < 16) *lds_bytes = 16;
     return RT_OK;
 }
 
@@ -685,8 +697,11 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         return fail(RT_ERR_INVALID, "strip too large");
 
     int block = 0, lds_bytes = 0, stack_lds_levels = 0;
-    int rc = choose_block(s, max_depth, &block, &lds_bytes, &stack_lds_levels);
+    bool global_tables = false;
+    int rc = choose_block(s, max_depth, &block, &lds_bytes, &stack_lds_levels, &global_tables);
     if (rc) return rc;
+    if (global_tables && d_stats)
+        return fail(RT_ERR_CAPACITY, "the counting build keeps the tables in LDS: this scene's do not fit (or option tables=2 is set)");
 
     RtParams p = s->base;
     for (int c = 0; c < 3; ++c) {
@@ -700,6 +715,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.W = W; p.H = H; p.x0 = x0; p.x1 = x1; p.max_depth = max_depth;
     p.stack_lds_levels = stack_lds_levels;
     p.stack_stride = block;
+    p.stack_off = global_tables ? 0 : s->base.image_quads;
     p.cull = s->cull_opt;
     /* Wavefront tile shape (speed only).  4 x 16 (x by z) makes every lane-row's
      * stores whole 64-byte sectors (16 pixels x 12 B = 192 B, aligned): measured
@@ -733,7 +749,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     /* deferred tiles (rt_tables.h): only scenes with clustered sphere runs have leaves to count */
     p.defer_leaves = 0;
     p.coop_off = 0;
-    if (s->n_clusters > 0 && s->cull_opt)
+    if (s->n_clusters > 0 && s->cull_opt && !global_tables)
         /* automatic: only when the launch renders a STRIP of the image (one GPU's share of a frame): there
          * the strip cannot finish before its longest tile, and the second pass cuts that tile to a quarter;
          * on a whole frame the heavy tiles are simply handed out first, and the second pass would only
@@ -743,7 +759,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
      * only the leader keeps a bounce stack; the cooperation area sits behind tables and stack */
     const int block2 = s->second_block_opt ? s->second_block_opt : block;
     const int stack_lds_levels2 = stack_lds_levels;              /* same levels in LDS, for 64 threads only */
-    const int coop_off = s->base.image_quads + stack_lds_levels2 * 64;
+    const int coop_off = p.stack_off + stack_lds_levels2 * 64;
     const size_t lds_bytes2 = ((size_t)coop_off + RT_COOP_QUADS(block2 / 64)) * 16;
     if (lds_bytes2 > RT_MAX_LDS_BYTES) p.defer_leaves = 0;      /* no room for the second pass's LDS area */
     p.n_tiles = (int)n_tiles;
@@ -752,7 +768,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
 
     s->launch.block_threads = block;
     s->launch.lds_bytes = lds_bytes;
-    s->launch.scene_lds_bytes = s->base.image_quads * 16;
+    s->launch.scene_lds_bytes = global_tables ? 0 : s->base.image_quads * 16;
     s->launch.tile_x = tile_x;
     s->launch.tile_z = tile_z;
     s->launch.grid_blocks = 0;
@@ -773,7 +789,8 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     }
     /* first-pass kernel: the plain one, or the one whose tiles may defer themselves */
     const void *first = d_stats ? (const void *)rt_render_kernel_stats
-                                : (p.defer_leaves != 0 ? (const void *)rt_render_kernel_deferring : (const void *)rt_render_kernel);
+                        : global_tables ? (const void *)rt_render_kernel_large
+                        : (p.defer_leaves != 0 ? (const void *)rt_render_kernel_deferring : (const void *)rt_render_kernel);
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, first, block, (size_t)lds_bytes));
     if (per_cu < 1) per_cu = 1;
@@ -827,6 +844,10 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
                            stream, p, reinterpret_cast<const float4 *>(s->d_image),
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
+    else if (global_tables)
+        hipLaunchKernelGGL(rt_render_kernel_large, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
+                           p, reinterpret_cast<const float4 *>(s->d_image),
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
     else if (p.defer_leaves != 0)
         hipLaunchKernelGGL(rt_render_kernel_deferring, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
@@ -1028,7 +1049,6 @@ int rt_reset_timing(rt_scene *s) {
 int rt_get_launch_info(const rt_scene *s, rt_launch_info *out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "scene/out is NULL");
     *out = s->launch;
-    out->scene_lds_bytes = s->base.image_quads * 16;
     if (s->launch.deferred_tiles >= 0 && s->d_defer) {
         unsigned int n = 0;
         HIP_TRY(hipSetDevice(s->device));
@@ -1063,6 +1083,11 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "first_row")) {
         if (value < -1 || value > 999) return fail(RT_ERR_INVALID, "first_row is in thousandths of the image height, [0, 999], or -1 (automatic)");
         s->first_row_permille = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "tables")) {
+        if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tables must be 0 (auto), 1 (LDS) or 2 (global memory)");
+        s->tables_opt = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "second_block")) {

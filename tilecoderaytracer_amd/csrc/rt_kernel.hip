@@ -560,7 +560,7 @@ __device__ __forceinline__ bool some_ray_needs_most_leaves(const float4 *items, 
 
 /* kMode: 0 a first-pass tile that never defers itself, 2 one that may, 3 the leader of a second-pass workgroup */
 template <bool kStats, int kMode>
-__device__ __forceinline__ void nearest_hit_items(const RtParams &p, float4 *lds, const bool active,
+__device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, float4 *wlds, const bool active,
                                                   const V3 o, const V3 d, const bool have_origin_box,
                                                   const V3 origins_lo, const V3 origins_hi,
                                                   float *best_out, int *best_idx_out, Stats<kStats> &st,
@@ -685,7 +685,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, float4 *lds
                 /* the workgroup shares these leaves (DEFERRED tiles above) */
                 mask &= ~leaf_mask;
                 if (lane >= plain) key = 0xFFFFFFFFu;               /* not the ordered loop's business */
-                float4 *coop = lds + p.coop_off;
+                float4 *coop = wlds + p.coop_off;
                 const int n_shares = (int)(blockDim.x >> 6);
                 coop[RT_COOP_RAY0 + lane] = make_float4(o.x, o.y, o.z, best);
                 coop[RT_COOP_RAY1 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(active ? (uint32_t)best_idx : RT_COOP_IDLE));
@@ -819,7 +819,7 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
 }
 
 template <bool kStats, int kMode>
-__device__ __forceinline__ bool in_shade(const RtParams &p, float4 *lds, const bool active,
+__device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, float4 *wlds, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
                                          const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
                                          bool *defer) {
@@ -883,7 +883,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, float4 *lds, const b
             } else if (__popcll(leaf_mask) >= RT_COOP_MIN_LEAVES) {
                 /* the workgroup shares these leaves (DEFERRED tiles, above nearest_hit_items()) */
                 mask &= ~leaf_mask;
-                float4 *coop = lds + p.coop_off;
+                float4 *coop = wlds + p.coop_off;
                 const int n_shares = (int)(blockDim.x >> 6);
                 coop[RT_COOP_RAY0 + lane] = make_float4(o.x, o.y, o.z, dist_to_light);
                 coop[RT_COOP_RAY1 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(blocked ? RT_COOP_IDLE : 1u));
@@ -1029,7 +1029,7 @@ __device__ __forceinline__ size_t hbm_stack_entry(const RtParams &p, const int l
 /* One wavefront tile: camera rays, the bounce loop, the unwind, the store.  Returns true
  * if the tile deferred itself (kMode 2; nothing is stored then). */
 template <bool kStats, int kMode>
-__device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, float *__restrict__ out,
+__device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float *__restrict__ out,
                                             float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
                                             Stats<kStats> &st, const int wave, const int my_xcc, const int steal) {
     constexpr bool kMayDefer = kMode == 2;
@@ -1087,7 +1087,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
         const unsigned long long t_scan = st_clock<kStats>();
-        nearest_hit_items<kStats, kMode>(p, lds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, &defer);   /* whole wavefront, converged */
+        nearest_hit_items<kStats, kMode>(p, lds, wlds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, &defer);   /* whole wavefront, converged */
         if (kMayDefer && defer) alive = false;                /* deferred: nothing more to trace, nothing to store */
         st_cycles(st, ST_CYCLES_NEAREST, t_scan);
         const unsigned long long t_winner = st_clock<kStats>();
@@ -1163,7 +1163,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
-                const bool blocked = in_shade<kStats, kMode>(p, lds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
+                const bool blocked = in_shade<kStats, kMode>(p, lds, wlds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
                 if (kMayDefer && defer) { shade = false; alive = false; }
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
@@ -1217,7 +1217,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
                 float4 e;
                 e.x = C.x; e.y = C.y; e.z = C.z;
                 e.w = __uint_as_float((uint32_t)idx | ((uint32_t)texsel << 16));
-                if (level < p.stack_lds_levels) lds[here(p.image_quads) + level * here(p.stack_stride) + threadIdx.x] = e;
+                if (level < p.stack_lds_levels) wlds[here(p.stack_off) + level * here(p.stack_stride) + threadIdx.x] = e;
                 else                            bounce_stack[hbm_stack_entry(p, level)] = e;
                 top = level + 1;
                 o = P;
@@ -1235,7 +1235,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
     for (int k = levels - 1; k >= 0; --k) {
         if (k < top) {
             float4 e;
-            if (k < p.stack_lds_levels) e = lds[here(p.image_quads) + k * here(p.stack_stride) + threadIdx.x];
+            if (k < p.stack_lds_levels) e = wlds[here(p.stack_off) + k * here(p.stack_stride) + threadIdx.x];
             else                        e = bounce_stack[hbm_stack_entry(p, k)];
             const uint32_t bits = __float_as_uint(e.w);
             const uint32_t info = lds_u32[p.objinfo_off * 4 + (bits & 0xFFFFu)];
@@ -1277,22 +1277,29 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, float4 *lds, floa
     return defer;
 }
 
-template <bool kStats, bool kSecondPass, bool kMayDefer>
+template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack,
                                             unsigned long long *__restrict__ stats_out,
                                             unsigned int *__restrict__ defer_list) {
-    extern __shared__ float4 lds[];
+    extern __shared__ float4 wlds[];                          /* LDS: the tables, the low levels of the bounce stack, the second pass's area */
     if (kSecondPass && defer_list[0] == 0u) return;          /* nothing was deferred */
     Stats<kStats> st;
     if constexpr (kStats) {
         for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
     }
 
-    /* stage the scene tables: global -> LDS, once per workgroup */
-    for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) lds[q] = image[q];
-    __syncthreads();
+    /* stage the scene tables: global -> LDS, once per workgroup.  The large-scene kernel
+     * (kGlobalTables) leaves them where they are: every table read of the scans has the same
+     * address in all lanes of a wavefront, so it is one 16-byte request to the XCD's L2, which
+     * holds a scene of any size the ABI admits -- no capacity limit, and LDS (hence occupancy)
+     * is spent on the bounce stack only. */
+    const float4 *lds = kGlobalTables ? image : wlds;
+    if constexpr (!kGlobalTables) {
+        for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) wlds[q] = image[q];
+        __syncthreads();
+    }
 
     /* Bounce stack, [level][threadIdx.x], one 16-byte entry per reflective level
      * per lane.  The lowest levels -- the ones nearly every chain uses -- live in
@@ -1327,7 +1334,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
   if constexpr (kSecondPass) {
     /* second pass: the workgroup renders one deferred tile at a time (DEFERRED tiles, above) */
-    float4 *coop = lds + p.coop_off;
+    float4 *coop = wlds + p.coop_off;
     const int my_wave = (int)(threadIdx.x >> 6), n_waves = (int)(blockDim.x >> 6);
     if (my_wave == 0) {
         const int n_deferred = (int)defer_list[0];
@@ -1338,7 +1345,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             const int pop = __builtin_amdgcn_readfirstlane(next_pop);
             if (pop >= n_deferred) break;
             if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-            (void)render_tile<kStats, 3>(p, lds, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
+            (void)render_tile<kStats, 3>(p, lds, wlds, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
         }
         if (lane == 0) coop[RT_COOP_CMD] = make_float4(__uint_as_float(0u), 0.0f, 0.0f, 0.0f);     /* exit */
         __syncthreads();
@@ -1398,7 +1405,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
     if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
-    if (render_tile<kStats, kMayDefer ? 2 : 0>(p, lds, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
+    if (render_tile<kStats, kMayDefer ? 2 : 0>(p, lds, wlds, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
         /* the tile deferred itself: the second pass renders it */
         if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
     }
@@ -1421,6 +1428,14 @@ rt_render_kernel(const RtParams p, const float4 *__restrict__ image, float *__re
                  unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                  unsigned int *__restrict__ defer_list) {
     render_body<false, false, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+}
+
+/* scenes whose tables are large (or do not fit LDS at all): the tables stay in global memory */
+extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
+rt_render_kernel_large(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                       unsigned int *__restrict__ defer_list) {
+    render_body<false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
 /* the first pass for scenes whose tiles may defer themselves (clustered sphere runs) ... */

@@ -92,6 +92,9 @@
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
 #define RT_MAX_OBJECTS    4096    /* 12-bit Scene index in the item tables */
 #define RT_MAX_LDS_BYTES  (160 * 1024)
+#ifndef RT_LDS_TABLE_BYTES
+#define RT_LDS_TABLE_BYTES (80 * 1024)   /* automatic: larger tables than this stay in global memory (rt_render_kernel_large) */
+#endif
 #ifndef RT_STACK_LDS_SHARE
 #define RT_STACK_LDS_SHARE 7      /* tables + the LDS part of the bounce stack must fit this many times per CU */
 #endif
@@ -140,6 +143,7 @@ typedef struct RtParams {
     int32_t tiles_z;                     /* wavefront tiles along z */
     int32_t tiles_x;                     /* wavefront tiles along x */
     int32_t n_tiles;                     /* total wavefront tiles   */
+    int32_t stack_off;                   /* quad offset of the bounce stack's LDS levels: behind the tables, or 0 when the tables stay in global memory */
     int32_t stack_stride;                /* threads that keep a bounce stack per workgroup: all of them, or 64 (the leader) in the second pass */
     int32_t stack_lds_levels;            /* bounce levels below this keep their stack entries in LDS (behind the tables), the others in HBM */
     int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around ... */
