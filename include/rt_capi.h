@@ -157,13 +157,15 @@ int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W,
  *     (shadow scans included) and the reflection step
  *   14, 15, 16 shadow scans: items left by the bundle cull, leaves some lane
  *     needed, and (summed over scans) the most leaves one lane needed
+ *   17, 18, 19, 20 nearest-hit scans (wavefronts) by how many of the 64 lanes traced
+ *     a ray: 1-16, 17-32, 33-48, 49-64 (what bounce compaction could merge)
  * wave_cycles (may be NULL) receives, per wavefront tile in row-major order
  * (tile = tile_row * tiles_x + tile_col), six words {shader cycles the
  * wavefront was resident, sphere tests it issued, box tests it issued, scans
  * it ran, start and end time on the 100 MHz constant clock}, up to
  * n_wave_cycles words.  out_rgb may be NULL.  The reference has no
  * counterpart (its gprof figures are quoted in SURVEY.md section 3.3). */
-#define RT_STATS_COUNT 17
+#define RT_STATS_COUNT 21
 int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                     int max_depth, float *out_rgb, uint64_t *stats, int n_stats,
                     uint64_t *wave_cycles, int n_wave_cycles);

@@ -97,6 +97,10 @@ enum {
     ST_SHADOW_CANDIDATES,   /* wavefronts: items left by the shadow scans' bundle cull      */
     ST_SHADOW_LEAVES_UNION, /* wavefronts: leaves some lane's segment needed                */
     ST_SHADOW_LEAVES_MAXLANE, /* wavefronts: per scan, the most leaves one lane needed      */
+    ST_NEAREST_1_16,        /* wavefronts: nearest-hit scans with 1-16 lanes tracing a ray, ... */
+    ST_NEAREST_17_32,
+    ST_NEAREST_33_48,
+    ST_NEAREST_49_64,       /* ... with 49-64 */
     ST_COUNT
 };
 template <bool kStats> struct Stats { };
@@ -1087,6 +1091,10 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
         int idx = 0, texsel = 0;     /* winner: Scene index and texture selector (material is re-read when needed) */
         float t = 0.0f;
         const unsigned long long t_scan = st_clock<kStats>();
+        if constexpr (kStats) {
+            const int n_alive = __popcll(__builtin_amdgcn_ballot_w64(alive));
+            st_wave(st, n_alive <= 16 ? ST_NEAREST_1_16 : n_alive <= 32 ? ST_NEAREST_17_32 : n_alive <= 48 ? ST_NEAREST_33_48 : ST_NEAREST_49_64);
+        }
         nearest_hit_items<kStats, kMode>(p, lds, wlds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, &defer);   /* whole wavefront, converged */
         if (kMayDefer && defer) alive = false;                /* deferred: nothing more to trace, nothing to store */
         st_cycles(st, ST_CYCLES_NEAREST, t_scan);
@@ -1287,6 +1295,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     if (kSecondPass && defer_list[0] == 0u) return;          /* nothing was deferred */
     Stats<kStats> st;
     if constexpr (kStats) {
+#pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) st.c[k] = 0u;
     }
 
@@ -1413,10 +1422,20 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
   }   /* next queue */
   }
     if constexpr (kStats) {
+#pragma unroll
         for (int k = 0; k < ST_COUNT; ++k)
             if (st.c[k]) atomicAdd(&stats_out[k], (unsigned long long)st.c[k]);
     }
 }
+
+/* The kernels read RtParams where they use it, through the kernarg segment pointer (the struct
+ * is the first kernel argument): handed to the body as a by-value argument, its ~70 dwords are
+ * all loaded at kernel entry and stay live in scalar registers, which left the scans to spill 85
+ * SGPRs to VGPR lanes (v_writelane / v_readlane plus their wait states in the loops); read on
+ * demand (s_load through the scalar cache) the kernel spills 22 and needs no scratch. */
+#define RT_PARAMS_FROM_KERNARG(name, by_value)                                                      \
+    (void)by_value;                                                                                 \
+    const RtParams &name = *(const RtParams *)(__builtin_amdgcn_kernarg_segment_ptr())
 
 /* 72 VGPRs: seven wavefronts per SIMD where LDS allows (the bounce stack keeps
  * its LDS place up to six workgroups per CU, RT_STACK_LDS_SHARE) */
@@ -1424,17 +1443,19 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 #define RT_WAVES_PER_SIMD 7
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
-rt_render_kernel(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+rt_render_kernel(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                  unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                  unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
 /* scenes whose tables are large (or do not fit LDS at all): the tables stay in global memory */
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
-rt_render_kernel_large(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+rt_render_kernel_large(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                        unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                        unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
@@ -1443,31 +1464,35 @@ rt_render_kernel_large(const RtParams p, const float4 *__restrict__ image, float
 #define RT_WAVES_PER_SIMD_DEFERRING 6
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_DEFERRING)
-rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+rt_render_kernel_deferring(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                            unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                            unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
 /* ... and the second pass: the deferred tiles, one per workgroup (of up to 8 wavefronts) at a time */
 extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_second(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+rt_render_kernel_second(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                         unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                         unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, true, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
 /* the counting builds: same arithmetic and control flow plus work counters */
 extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+rt_render_kernel_stats(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                        unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                        unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<true, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
 }
 
 extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_second_stats(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out,
+rt_render_kernel_second_stats(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                               unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                               unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<true, true, false>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
 }

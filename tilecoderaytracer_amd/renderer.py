@@ -58,7 +58,8 @@ class Renderer:
                   "wave_sphere_tests", "wave_plane_tests", "wave_box_tests", "lane_sphere_tests",
                   "cycles_nearest", "cycles_shadow", "cycles_tile",
                   "cycles_winner", "cycles_lights", "cycles_reflect",
-                  "shadow_candidates", "shadow_leaves_union", "shadow_leaves_maxlane")
+                  "shadow_candidates", "shadow_leaves_union", "shadow_leaves_maxlane",
+                  "nearest_scans_1_16", "nearest_scans_17_32", "nearest_scans_33_48", "nearest_scans_49_64")
 
     def render_stats(self, W, H, max_depth, x0=0, x1=None, wave_cycles=False):
         """Counting build: returns (image, {counter: value}[, per wavefront tile (tiles_z, tiles_x, 6) = cycles, sphere tests, box tests, scans, start, end (100 MHz)])."""
