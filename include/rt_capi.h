@@ -143,6 +143,12 @@ int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, int W, int H,
 int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
                     int max_depth, int ngpu, float *out_rgb);
 
+/* The partition rt_render_multi uses: strip g of ngpu equal x-strips of ceil(W / ngpu) columns is
+ * columns [*x0, *x1) (trailing strips may be short or empty); returns the strip width, which is also
+ * the column stride of the strips in the gathered buffer (rank g at g * width: only trailing strips
+ * are short, so columns [0, W) are contiguous at its start).  Returns 0 on bad arguments. */
+int rt_strip_bounds(int W, int ngpu, int g, int *x0, int *x1);
+
 /* Diagnostic "counting build" of rt_render (same arithmetic and control flow,
  * plus work counters; slower).  stats[k], k < RT_STATS_COUNT:
  *   0 nearest-hit rays (lanes)        1 shadow rays (lanes)

@@ -226,3 +226,36 @@ def test_measured_partition_is_agreed_on_and_delivers_the_image(oracle):
     assert b[0][0] == 0 and b[-1][1] == W and (b[1][1] - b[1][0]) < 16      # the costly strip got narrower
     ref = oracle.OracleScene.builtin().render(W, H, 2)
     np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_rt_render_multi_strip_arithmetic(oracle):
+    """rt_render_multi (one process, N GPUs) on the CPU, with the oracle standing in for the
+    kernel: every "GPU" renders the strip rt_strip_bounds gives it into its own strip-sized
+    buffer, the gather places rank g at g * strip_floats of the full buffer (what ncclGather
+    does at the root), and the first W * H * 3 floats of that buffer are the image
+    (csrc/rt_multi.hip).  Widths that do not divide, short and empty trailing strips."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    lib = capi.load_library()
+    H, depth = 12, 2
+    scene = oracle.OracleScene.builtin()
+    for W, n in ((64, 2), (64, 8), (37, 2), (37, 3), (5, 8), (9, 4), (1, 2), (100, 7)):
+        want = scene.render(W, H, depth)
+        strip = lib.rt_strip_bounds(W, n, 0, None, None)
+        assert strip == -(-W // n)
+        full = np.full((n * strip, H, 3), -7.0, np.float32)          # the root's receive buffer
+        covered = 0
+        for g in range(n):
+            x0, x1 = C.c_int(), C.c_int()
+            assert lib.rt_strip_bounds(W, n, g, C.byref(x0), C.byref(x1)) == strip
+            x0, x1 = x0.value, x1.value
+            assert 0 <= x0 <= x1 <= W and x0 == min(g * strip, W) and x1 - x0 <= strip
+            assert x0 == covered                                      # contiguous, in rank order
+            covered = x1
+            mine = np.full((strip, H, 3), -9.0, np.float32)           # this rank's send buffer: strip_floats floats
+            mine[: x1 - x0] = scene.render(W, H, depth, x0, x1)
+            full[g * strip:(g + 1) * strip] = mine                    # ncclGather: rank g at g * sendcount
+        assert covered == W
+        image = full.reshape(-1)[: W * H * 3].reshape(W, H, 3)        # the image_bytes copy to the caller
+        assert np.array_equal(image.view(np.uint32), want.view(np.uint32)), (W, n)
+    assert lib.rt_strip_bounds(0, 2, 0, None, None) == 0 and lib.rt_strip_bounds(8, 2, 2, None, None) == 0

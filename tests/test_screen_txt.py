@@ -45,6 +45,15 @@ def test_header_lines(tmp_path):
     assert lines[10:16] == ["(0.000000, 0.000000, 0.000000)"] * 6 and lines[16] == ""
 
 
+def test_header_names_the_gpus_and_the_partition(tmp_path):
+    """--gpus G: CORE_NUM = G and the static partition's label (src/RayTracer.cpp:2037-2058)."""
+    p = str(tmp_path / "raytracer_screen.txt")
+    write_screen_txt(p, np.zeros((2, 3, 3), np.float32), 0.5, 7.0, n_cores=8)
+    lines = open(p).read().split("\n")
+    assert lines[4] == "Number_of_Cores:8." and lines[6] == "DUMB_STATIC_PARTIONING"
+    assert lines[:4] == ["OSX Awesome Picture", "Horizontal_Resolution:2.", "Vertical_Resolution:3.", "Hardware_Target:OSX C++."]
+
+
 def test_builtin_512_d3_text_md5_matches_the_reference(oracle, tmp_path):
     img = oracle.OracleScene.builtin().render(512, 512, 3)
     p = str(tmp_path / "raytracer_screen.txt")

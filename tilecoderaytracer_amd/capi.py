@@ -101,6 +101,8 @@ def load_library():
     lib.rt_render.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp]
     lib.rt_render_device.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, vp]
     lib.rt_render_multi.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), i, i, i, i, vp]
+    lib.rt_strip_bounds.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+    lib.rt_strip_bounds.restype = i
     lib.rt_render_stats.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, C.POINTER(C.c_uint64), i, vp, i]
     lib.rt_get_timing.argtypes = [vp, C.POINTER(RtTiming)]
     lib.rt_reset_timing.argtypes = [vp]

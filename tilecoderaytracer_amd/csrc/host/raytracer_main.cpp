@@ -128,7 +128,7 @@ int main(int argc, char **argv) {
         std::printf("PrintScreen to Log.\n");
         std::printf("Greetings: %d, %d \n", W, H);
         if (celio_write_screen_txt(out_path.c_str(), W, H, pixels.data(), run_time_s,
-                                   run_time_us / ((double)W * (double)H)))
+                                   run_time_us / ((double)W * (double)H), gpus))
             return 1;
         std::printf("Closing log file.\n\n");
     }

@@ -174,4 +174,9 @@ int rth_write_screen_txt(const char *path, int W, int H, const float *rgb, doubl
     return celio_write_screen_txt(path, W, H, rgb, run_time_s, us_per_pixel);
 }
 
+int rth_write_screen_txt_cores(const char *path, int W, int H, const float *rgb, double run_time_s,
+                               double us_per_pixel, int n_cores) {
+    return celio_write_screen_txt(path, W, H, rgb, run_time_s, us_per_pixel, n_cores);
+}
+
 } // extern "C"

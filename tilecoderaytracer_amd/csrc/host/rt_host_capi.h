@@ -50,6 +50,10 @@ const rt_camera_desc *rth_camera_desc(rth_scene *s);
 /* byte-exact raytracer_screen.txt (src/RayTracer.cpp:2022-2061, 1574-1626) */
 int rth_write_screen_txt(const char *path, int W, int H, const float *rgb,
                          double run_time_s, double us_per_pixel);
+/* the same with CORE_NUM = n_cores in the header (one "core" per GPU; > 1 writes the static
+ * partition's label, src/RayTracer.cpp:2037-2058) */
+int rth_write_screen_txt_cores(const char *path, int W, int H, const float *rgb,
+                               double run_time_s, double us_per_pixel, int n_cores);
 
 #ifdef __cplusplus
 }

@@ -69,7 +69,7 @@ inline char *format_f(char *dst, float v) {
 
 /* returns 0 ok / 1 error, like init_log() */
 inline int celio_write_screen_txt(const char *path, int W, int H, const float *rgb,
-                                  double run_time_s, double us_per_pixel) {
+                                  double run_time_s, double us_per_pixel, int n_cores = 1) {
     if (!path || W < 0 || H < 0 || (!rgb && (size_t)W * (size_t)H > 0)) return 1;
     std::FILE *f = std::fopen(path, "w");
     if (!f) {
@@ -80,9 +80,11 @@ inline int celio_write_screen_txt(const char *path, int W, int H, const float *r
     std::fprintf(f, "Horizontal_Resolution:%i.\n", W);
     std::fprintf(f, "Vertical_Resolution:%i.\n", H);
     std::fprintf(f, "Hardware_Target:%s.\n", "OSX C++");        /* HARDWARE_TARGET, :21 */
-    std::fprintf(f, "Number_of_Cores:%i.\n", 1);
+    /* CORE_NUM and the PARTIONING_STRATEGY label, src/RayTracer.cpp:2037-2058: one "core" per GPU;
+     * more than one means the static strip partition (strategy 1, DUMB_STATIC_PARTIONING) */
+    std::fprintf(f, "Number_of_Cores:%i.\n", n_cores);
     std::fputs("IS_FOR_HARDWARE\n", f);
-    std::fputs("NO_PARTIONING\n", f);
+    std::fputs(n_cores > 1 ? "DUMB_STATIC_PARTIONING\n" : "NO_PARTIONING\n", f);
     std::fprintf(f, "Run_Time:%f.\n", run_time_s);
     std::fprintf(f, "us/pixel:%f.\n", us_per_pixel);
     std::fprintf(f, "filename:%s.\n", "raytracer_screen.txt");

@@ -68,6 +68,14 @@ bool load_rccl(Rccl &r, std::string &err) {
 /* defined in rt_capi.hip: stores the message for rt_last_error() */
 extern "C" int rt_internal_set_error(int code, const char *msg);
 
+extern "C" int rt_strip_bounds(int W, int ngpu, int g, int *x0, int *x1) {
+    if (W <= 0 || ngpu <= 0 || g < 0 || g >= ngpu) return 0;
+    const int strip = (W + ngpu - 1) / ngpu;
+    if (x0) *x0 = (long long)g * strip < W ? g * strip : W;
+    if (x1) *x1 = ((long long)g + 1) * strip < W ? (g + 1) * strip : W;
+    return strip;
+}
+
 extern "C" int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
                                int max_depth, int ngpu, float *out_rgb) {
     if (!desc || !cam || !out_rgb) return rt_internal_set_error(RT_ERR_INVALID, "desc/cam/out_rgb is NULL");
@@ -80,7 +88,7 @@ extern "C" int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *
     /* equal strips of ceil(W / ngpu) columns; trailing strips may be short or
      * empty.  Because only trailing strips are short, columns [0, W) are
      * contiguous at the start of the gathered buffer. */
-    const int strip = (W + ngpu - 1) / ngpu;
+    const int strip = rt_strip_bounds(W, ngpu, 0, nullptr, nullptr);
     const size_t strip_floats = (size_t)strip * (size_t)H * 3;
 
     std::vector<rt_scene *> scenes((size_t)ngpu, nullptr);
@@ -141,8 +149,8 @@ extern "C" int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *
 
     /* render: every GPU its strip, concurrently, each on its own stream */
     for (int g = 0; g < ngpu; ++g) {
-        const int x0 = g * strip < W ? g * strip : W;
-        const int x1 = (g + 1) * strip < W ? (g + 1) * strip : W;
+        int x0 = 0, x1 = 0;
+        (void)rt_strip_bounds(W, ngpu, g, &x0, &x1);
         rc = rt_render_device(scenes[(size_t)g], cam, W, H, x0, x1, max_depth, d_strip[(size_t)g],
                               streams[(size_t)g]);
         if (rc) { cleanup(); return rc; }

@@ -54,6 +54,7 @@ def load_host_library():
     lib.rth_camera_desc.argtypes = [vp]
     lib.rth_camera_desc.restype = C.POINTER(RtCameraDesc)
     lib.rth_write_screen_txt.argtypes = [C.c_char_p, i, i, vp, C.c_double, C.c_double]
+    lib.rth_write_screen_txt_cores.argtypes = [C.c_char_p, i, i, vp, C.c_double, C.c_double, i]
     _hlib = lib
     return lib
 
@@ -171,12 +172,13 @@ class HostScene:
         return self._lib.rth_camera_desc(self._h)
 
 
-def write_screen_txt(path, rgb, run_time_s=0.0, us_per_pixel=0.0):
-    """Write ``raytracer_screen.txt`` for a (W, H, 3) float32 array."""
+def write_screen_txt(path, rgb, run_time_s=0.0, us_per_pixel=0.0, n_cores=1):
+    """Write ``raytracer_screen.txt`` for a (W, H, 3) float32 array; n_cores = GPUs that rendered it
+    (CORE_NUM and the partition label of the header, src/RayTracer.cpp:2037-2058)."""
     import numpy as np
     a = np.ascontiguousarray(rgb, dtype=np.float32)
     W, H = a.shape[0], a.shape[1]
-    rc = load_host_library().rth_write_screen_txt(os.fsencode(path), W, H, a.ctypes.data,
-                                                  run_time_s, us_per_pixel)
+    rc = load_host_library().rth_write_screen_txt_cores(os.fsencode(path), W, H, a.ctypes.data,
+                                                        run_time_s, us_per_pixel, int(n_cores))
     if rc != 0:
         raise OSError(f"could not write {path}")
