@@ -30,7 +30,7 @@ for w in grid32 grid16d8; do
 done
 cd $R
 if [ $WHAT = all ]; then
-  for w in builtin grid32 grid16d8 grid32-noshadow builtin8k; do
+  for w in builtin grid32 grid16d8 grid32-noshadow builtin8k twomirrors; do
     python3 bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.log
   done
 fi

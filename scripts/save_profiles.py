@@ -76,7 +76,7 @@ with open(os.path.join(P, f"{tag}_grid32_pmc_sq.csv"), "w") as f:
         h, rs = rows(path)
         if first: wr.writerow(h); first = False
         wr.writerows(rs[-8:])
-for w in ("builtin", "grid32", "grid16d8", "grid32-noshadow", "builtin8k"):
+for w in ("builtin", "grid32", "grid16d8", "grid32-noshadow", "builtin8k", "twomirrors"):
     f = os.path.join(src, f"bench_{w}.json")
     if os.path.exists(f): shutil.copy(f, os.path.join(P, f"{tag}_bench_{w}.json"))
 print(json.dumps(traffic, indent=1)[:600])
