@@ -184,6 +184,10 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *   "tile_z"        wavefront tile height, 1,2,4,...,64 (width = 64 / height)
  *   "block_threads" 0 = auto, else 64, 128, 192 or 256
  *   "stack"         bounce stack: 0 auto, 1 LDS, 2 HBM
+ *   "pairs"         scenes with clustered sphere runs: 0 = every needed leaf is tested for
+ *                   the whole wavefront (round 1's route); 1 (default) = the (ray, leaf)
+ *                   pairs that the per-lane box tests leave are compacted into full
+ *                   wavefront rounds
  *   "tables"        where the kernel reads the scene tables: 1 = LDS (staged once per
  *                   workgroup; at most 160 KiB), 2 = global memory through the L2 (any
  *                   size), 0 = automatic (LDS up to 80 KiB)

@@ -644,6 +644,7 @@ def test_second_pass_does_not_change_results(oracle, name, W, H, depth, block):
     r = Renderer(HostScene.named(name))
     r.set_option("defer", 65)
     r.set_option("second_block", block)
+    r.set_option("tables", 1)                  # the second pass works from LDS tables (two mirrors: 119 KB, would default to global)
     assert_same(r.render(W, H, depth), want, f"{name} deferred, {block // 64} wavefronts")
     li = r.launch_info()
     assert li.deferred_tiles > 0 and li.slices == (block or 256) // 64

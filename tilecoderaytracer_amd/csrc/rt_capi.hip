@@ -31,6 +31,12 @@ extern "C" __global__ void rt_render_kernel_large(const RtParams p, const float4
                                                   float4 *__restrict__ bounce_stack,
                                                   unsigned int *__restrict__ defer_list);
 
+extern "C" __global__ void rt_render_kernel_clusters(const RtParams p, const float4 *__restrict__ image,
+                                                     float *__restrict__ out,
+                                                     unsigned int *__restrict__ tile_counter,
+                                                     float4 *__restrict__ bounce_stack,
+                                                     unsigned int *__restrict__ defer_list);
+
 extern "C" __global__ void rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image,
                                                       float *__restrict__ out,
                                                       unsigned int *__restrict__ tile_counter,
@@ -104,6 +110,7 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
+    int pairs_opt = 1;            /* scenes with clustered runs: the kernel that compacts (ray, leaf) pairs (0: the plain kernel) */
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int second_block_opt = 0;     /* threads per workgroup of the second pass: 0 = as the first pass, else 64..512 */
     int defer_opt = -1;           /* a scan with this many candidate leaves (most of them needed by some ray) defers its tile
@@ -790,7 +797,8 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     /* first-pass kernel: the plain one, or the one whose tiles may defer themselves */
     const void *first = d_stats ? (const void *)rt_render_kernel_stats
                         : global_tables ? (const void *)rt_render_kernel_large
-                        : (p.defer_leaves != 0 ? (const void *)rt_render_kernel_deferring : (const void *)rt_render_kernel);
+                        : p.defer_leaves != 0 ? (const void *)rt_render_kernel_deferring
+                        : (s->n_clusters > 0 && s->pairs_opt) ? (const void *)rt_render_kernel_clusters : (const void *)rt_render_kernel;
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, first, block, (size_t)lds_bytes));
     if (per_cu < 1) per_cu = 1;
@@ -846,6 +854,10 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
     else if (global_tables)
         hipLaunchKernelGGL(rt_render_kernel_large, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
+                           p, reinterpret_cast<const float4 *>(s->d_image),
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+    else if (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt)
+        hipLaunchKernelGGL(rt_render_kernel_clusters, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
     else if (p.defer_leaves != 0)
@@ -1083,6 +1095,10 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "first_row")) {
         if (value < -1 || value > 999) return fail(RT_ERR_INVALID, "first_row is in thousandths of the image height, [0, 999], or -1 (automatic)");
         s->first_row_permille = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "pairs")) {
+        s->pairs_opt = value != 0;
         return RT_OK;
     }
     if (!std::strcmp(key, "tables")) {

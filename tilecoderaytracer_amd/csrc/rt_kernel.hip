@@ -562,7 +562,8 @@ __device__ __forceinline__ bool some_ray_needs_most_leaves(const float4 *items, 
     return wave_any(asked >= 2 && 4 * needed >= 3 * asked);
 }
 
-/* kMode: 0 a first-pass tile that never defers itself, 2 one that may, 3 the leader of a second-pass workgroup */
+/* kMode: 0 a first-pass tile of a scene without clustered runs; 4 of a scene with them (PAIRS below); 2 one that may also
+ * defer itself; 3 the leader of a second-pass workgroup */
 template <bool kStats, int kMode>
 __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, float4 *wlds, const bool active,
                                                   const V3 o, const V3 d, const bool have_origin_box,
@@ -822,12 +823,68 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
     *centre = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
 }
 
+/* PAIRS (shadow scans of scenes with clustered sphere runs, kMode != 0).  The per-lane box
+ * tests leave, for every candidate leaf, the lanes whose ray needs it; testing the leaf's
+ * members for the whole wavefront then wastes the other lanes -- two thirds of them on the
+ * sphere-grid frames (profiles/: 0.32 of the issued sphere tests were needed by their lane),
+ * all but one or two when a single ray grazes the whole field.  So a leaf that fewer than
+ * RT_PAIR_DIRECT_LANES lanes need is not tested at once: its (ray, leaf) pairs are appended to a
+ * buffer of up to 63 SLOTS, one per lane -- the needing lanes push their lane number to the
+ * next free slots (ds_permute), the slots note the leaf -- and a full buffer is FLUSHED: every
+ * slot pulls its ray (ds_bpermute), walks its own leaf's members (per-lane LDS addresses,
+ * rotated by the leaf's position so that the slots do not meet in one LDS bank), and the
+ * verdicts go back to the rays' lanes.  The same sphere test on the same operands as the direct
+ * route, and blocking is an OR, so the result is the reference's (src/RayTracer.cpp:727-729). */
+#ifndef RT_PAIR_DIRECT_LANES
+#define RT_PAIR_DIRECT_LANES 40
+#endif
+struct ShadowPairs {
+    int src, geom, count;   /* per slot (= lane): the ray's lane, the leaf's first member quad, its member count */
+    int fill;               /* wave-uniform: slots in use */
+};
+
+__device__ __forceinline__ float lane_pull_f(const int byte_addr, const float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+template <bool kStats>
+__device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPairs &pb, const V3 o, const V3 d,
+                                                   const float dist_to_light, bool blocked, Stats<kStats> &st) {
+    if (pb.fill == 0) return blocked;
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool has = lane < pb.fill;
+    const int from = pb.src << 2;
+    const V3 po = mk(lane_pull_f(from, o.x), lane_pull_f(from, o.y), lane_pull_f(from, o.z));
+    const V3 pd = mk(lane_pull_f(from, d.x), lane_pull_f(from, d.y), lane_pull_f(from, d.z));
+    const float pdist = lane_pull_f(from, dist_to_light);
+    const int rot = pb.count == 16 ? ((pb.geom >> 4) & 15) : 0;
+    bool pair_blocked = false;
+    for (int i = 0; wave_any(has && i < pb.count); ++i) {
+        int j = i + rot;
+        j = j >= pb.count ? j - pb.count : j;
+        bool hit; float t;
+        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < pb.count);
+        sphere_distance(lds[pb.geom + j], po, pd, &hit, &t);
+        pair_blocked = pair_blocked || (has && i < pb.count && hit && t < pdist);
+    }
+    /* the verdicts, back to the rays' lanes (few pairs block) */
+    unsigned long long verdicts = __builtin_amdgcn_ballot_w64(pair_blocked);
+    while (verdicts != 0ull) {
+        const int slot = __ffsll((long long)verdicts) - 1;
+        verdicts &= verdicts - 1ull;
+        if (lane == __builtin_amdgcn_readlane(pb.src, slot)) blocked = true;
+    }
+    pb.fill = 0;
+    return blocked;
+}
+
 template <bool kStats, int kMode>
 __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, float4 *wlds, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
                                          const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
                                          bool *defer) {
-    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3;
+    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3, kPairs = kMode != 0;
+    ShadowPairs pairs = {0, 0, 0, 0};
     bool blocked = !active;
     int stat_my_leaves = 0;
     if (p.n_shadow_items == 0) return false;
@@ -921,9 +978,23 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                 const int n = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
-                if (!wave_any(lane_needs)) continue;
+                const unsigned long long needers = __builtin_amdgcn_ballot_w64(lane_needs);
+                if (needers == 0ull) continue;
                 st_wave(st, ST_SHADOW_LEAVES_UNION);
                 if constexpr (kStats) stat_my_leaves += lane_needs ? 1 : 0;
+                if (kPairs && __popcll(needers) < RT_PAIR_DIRECT_LANES) {      /* PAIRS, above */
+                    const int wanted = __popcll(needers);
+                    if (pairs.fill + wanted > 63) blocked = flush_shadow_pairs<kStats>(lds, pairs, o, d, dist_to_light, blocked, st);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needers, 0u));
+                    /* every lane sends; the ones that do not need the leaf send to lane 63, which is never a slot */
+                    const int who = __builtin_amdgcn_ds_permute((lane_needs ? pairs.fill + rank : 63) << 2, lane);
+                    const bool fresh = lane >= pairs.fill && lane < pairs.fill + wanted;
+                    pairs.src = fresh ? who : pairs.src;
+                    pairs.geom = fresh ? (int)(bits >> 16) : pairs.geom;
+                    pairs.count = fresh ? n : pairs.count;
+                    pairs.fill += wanted;
+                    continue;
+                }
 #pragma unroll 2
                 for (int i = 0; i < n; ++i) {
                     st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
@@ -968,6 +1039,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
         }
     }
     st_maxlane(st, ST_SHADOW_LEAVES_MAXLANE, stat_my_leaves);
+    if constexpr (kPairs) blocked = flush_shadow_pairs<kStats>(lds, pairs, o, d, dist_to_light, blocked, st);
     return blocked;
 }
 
@@ -1285,7 +1357,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
     return defer;
 }
 
-template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false>
+template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false, bool kClusters = false>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack,
@@ -1414,7 +1486,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
     if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
-    if (render_tile<kStats, kMayDefer ? 2 : 0>(p, lds, wlds, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
+    if (render_tile<kStats, kMayDefer ? 2 : (kClusters ? 4 : 0)>(p, lds, wlds, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
         /* the tile deferred itself: the second pass renders it */
         if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
     }
@@ -1459,9 +1531,21 @@ rt_render_kernel_large(const RtParams p_in_kernarg, const float4 *__restrict__ i
     render_body<false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
+/* scenes with clustered sphere runs (PAIRS): one more wavefront's worth of registers per lane */
+#ifndef RT_WAVES_PER_SIMD_CLUSTERS
+#define RT_WAVES_PER_SIMD_CLUSTERS 7
+#endif
+extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_CLUSTERS)
+rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
+                          unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                          unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
+    render_body<false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+}
+
 /* the first pass for scenes whose tiles may defer themselves (clustered sphere runs) ... */
 #ifndef RT_WAVES_PER_SIMD_DEFERRING
-#define RT_WAVES_PER_SIMD_DEFERRING 6
+#define RT_WAVES_PER_SIMD_DEFERRING 5
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_DEFERRING)
 rt_render_kernel_deferring(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
