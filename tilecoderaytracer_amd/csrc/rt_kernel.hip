@@ -101,6 +101,8 @@ enum {
     ST_NEAREST_17_32,
     ST_NEAREST_33_48,
     ST_NEAREST_49_64,       /* ... with 49-64 */
+    ST_NEAREST_UNCULLED,    /* wavefronts: nearest-hit scans whose bundle cull was skipped (directions all over) */
+    ST_NEAREST_UNCULLED_BOX,/* wavefronts: cluster box tests issued in those scans */
     ST_COUNT
 };
 template <bool kStats> struct Stats { };
@@ -594,7 +596,10 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
 #endif
         /* directions all over the place: the cone is everything, skip the cull */
         cull = !((dminx < 0.0f && dmaxx > 0.0f) && (dminy < 0.0f && dmaxy > 0.0f) && (dminz < 0.0f && dmaxz > 0.0f));
+        if (!cull) st_wave(st, ST_NEAREST_UNCULLED);
     }
+    const bool stat_unculled = !cull && p.cull != 0 && p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
+    (void)stat_unculled;
     float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
 #ifdef RT_BRANCHY_CULL
     float rnx = 0, rxx = 0, rny = 0, rxy = 0, rnz = 0, rxz = 0;
@@ -740,6 +745,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run; bits1 = its members' Scene indices */
                 const int n = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
+                if (stat_unculled) st_wave(st, ST_NEAREST_UNCULLED_BOX);
                 const bool lane_needs = active && box_needed(i0, i1, o, inv, best);
                 if (!wave_any(lane_needs)) continue;
                 const uint32_t *ids = lds_u32 + bits1;
