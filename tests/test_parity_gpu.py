@@ -775,3 +775,31 @@ def test_tables_option_that_does_not_fit_is_refused(oracle):
     assert e.value.code == capi.RT_ERR_CAPACITY
     r.set_option("tables", 0)
     assert r.render(8, 8, 2).shape == (8, 8, 3)
+
+
+def test_counting_build_of_a_clustered_scene_both_passes(oracle):
+    """rt_render_stats on a scene with clustered runs: the counting variants of the first-pass and of the
+    second-pass kernel (forced deferral) must render the oracle's image too, and count the same rays."""
+    want = oracle.OracleScene.grid(16, True).render(96, 80, 6)
+    counters = oracle.OracleScene.counters()
+    for defer in (0, 65):
+        r = Renderer(HostScene.grid(16, True))
+        r.set_option("defer", defer)
+        img, st = r.render_stats(96, 80, 6)
+        assert_same(img, want, f"counting build, defer {defer}")
+        if defer == 0:
+            assert st["nearest_rays"] == counters.nearest_rays and st["shadow_rays"] == counters.shadow_rays
+            assert st["nearest_scans_1_16"] + st["nearest_scans_17_32"] + st["nearest_scans_33_48"] + st["nearest_scans_49_64"] == st["wave_nearest_scans"]
+        else:
+            assert r.launch_info().deferred_tiles > 0
+
+
+def test_counting_build_refuses_tables_it_cannot_hold(oracle):
+    from tilecoderaytracer_amd import RtError, capi
+    r = Renderer(HostScene.two_mirrors())                 # 119 KB of tables: global memory by default
+    with pytest.raises(RtError) as e:
+        r.render_stats(16, 16, 2)
+    assert e.value.code == capi.RT_ERR_CAPACITY
+    r.set_option("tables", 1)                              # they do fit LDS
+    img, _ = r.render_stats(16, 16, 2)
+    assert_same(img, oracle.OracleScene.two_mirrors().render(16, 16, 2), "counting build, two mirrors in LDS")
