@@ -30,6 +30,9 @@ for w in grid32 grid16d8; do
 done
 cd $R
 if [ $WHAT = all ]; then
+  # counters first into profiles/pmc_traffic.json (with the kernel-source digest), so that the bench lines
+  # below can report roofline.traffic / roofline.compute from the same build
+  python3 scripts/save_profiles.py $O r02 > $O/save_profiles.log 2>&1 || true
   for w in builtin grid32 grid16d8 grid32-noshadow builtin8k twomirrors; do
     python3 bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.log
   done

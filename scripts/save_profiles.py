@@ -23,7 +23,8 @@ def counter(path):
         out[r[i]] = float(r[j])          # last dispatch wins
     return out
 
-shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(P, f"{tag}_builtin4096d4_kernel_stats.csv"))
+f0 = one("trace/*/*_kernel_stats.csv")
+if f0: shutil.copy(f0, os.path.join(P, f"{tag}_builtin4096d4_kernel_stats.csv"))
 for w in ("grid32", "grid16d8"):
     f = one(f"trace_{w}/*/*_kernel_stats.csv")
     if f: shutil.copy(f, os.path.join(P, f"{tag}_{w}_kernel_stats.csv"))

@@ -37,6 +37,12 @@ extern "C" __global__ void rt_render_kernel_clusters(const RtParams p, const flo
                                                      float4 *__restrict__ bounce_stack,
                                                      unsigned int *__restrict__ defer_list);
 
+extern "C" __global__ void rt_render_kernel_clusters_wide(const RtParams p, const float4 *__restrict__ image,
+                                                          float *__restrict__ out,
+                                                          unsigned int *__restrict__ tile_counter,
+                                                          float4 *__restrict__ bounce_stack,
+                                                          unsigned int *__restrict__ defer_list);
+
 extern "C" __global__ void rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image,
                                                       float *__restrict__ out,
                                                       unsigned int *__restrict__ tile_counter,
@@ -794,11 +800,15 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    /* first-pass kernel: the plain one, or the one whose tiles may defer themselves */
+    /* first-pass kernel: the plain one, the one for clustered scenes (in the register budget that fits the
+     * occupancy LDS allows), the large-scene one, or the one whose tiles may defer themselves */
+    const bool clusters_wide = (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
     const void *first = d_stats ? (const void *)rt_render_kernel_stats
                         : global_tables ? (const void *)rt_render_kernel_large
                         : p.defer_leaves != 0 ? (const void *)rt_render_kernel_deferring
-                        : (s->n_clusters > 0 && s->pairs_opt) ? (const void *)rt_render_kernel_clusters : (const void *)rt_render_kernel;
+                        : (s->n_clusters > 0 && s->pairs_opt)
+                              ? (clusters_wide ? (const void *)rt_render_kernel_clusters_wide : (const void *)rt_render_kernel_clusters)
+                              : (const void *)rt_render_kernel;
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, first, block, (size_t)lds_bytes));
     if (per_cu < 1) per_cu = 1;
@@ -854,6 +864,10 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
     else if (global_tables)
         hipLaunchKernelGGL(rt_render_kernel_large, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
+                           p, reinterpret_cast<const float4 *>(s->d_image),
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+    else if (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt && clusters_wide)
+        hipLaunchKernelGGL(rt_render_kernel_clusters_wide, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
                            d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
     else if (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt)

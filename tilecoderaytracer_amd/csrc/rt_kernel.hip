@@ -836,7 +836,7 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
  * all but one or two when a single ray grazes the whole field.  So a leaf that fewer than
  * RT_PAIR_DIRECT_LANES lanes need is not tested at once: its (ray, leaf) pairs are appended to a
  * buffer of up to 63 SLOTS, one per lane -- the needing lanes push their lane number to the
- * next free slots (ds_permute), the slots note the leaf -- and a full buffer is FLUSHED: every
+ * next free slots (ds_permute), the slots note the leaf (one packed word per slot) -- and a full buffer is FLUSHED: every
  * slot pulls its ray (ds_bpermute), walks its own leaf's members (per-lane LDS addresses,
  * rotated by the leaf's position so that the slots do not meet in one LDS bank), and the
  * verdicts go back to the rays' lanes.  The same sphere test on the same operands as the direct
@@ -845,7 +845,7 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
 #define RT_PAIR_DIRECT_LANES 40
 #endif
 struct ShadowPairs {
-    int src, geom, count;   /* per slot (= lane): the ray's lane, the leaf's first member quad, its member count */
+    int slot;               /* per slot (= lane): the ray's lane | member count << 6 | the leaf's first member quad << 11 */
     int fill;               /* wave-uniform: slots in use */
 };
 
@@ -859,26 +859,27 @@ __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPair
     if (pb.fill == 0) return blocked;
     const int lane = (int)(threadIdx.x & 63u);
     const bool has = lane < pb.fill;
-    const int from = pb.src << 2;
+    const int src = pb.slot & 63, count = (pb.slot >> 6) & 31, geom = pb.slot >> 11;
+    const int from = src << 2;
     const V3 po = mk(lane_pull_f(from, o.x), lane_pull_f(from, o.y), lane_pull_f(from, o.z));
     const V3 pd = mk(lane_pull_f(from, d.x), lane_pull_f(from, d.y), lane_pull_f(from, d.z));
     const float pdist = lane_pull_f(from, dist_to_light);
-    const int rot = pb.count == 16 ? ((pb.geom >> 4) & 15) : 0;
+    const int rot = count == 16 ? ((geom >> 4) & 15) : 0;
     bool pair_blocked = false;
-    for (int i = 0; wave_any(has && i < pb.count); ++i) {
+    for (int i = 0; wave_any(has && i < count); ++i) {
         int j = i + rot;
-        j = j >= pb.count ? j - pb.count : j;
+        j = j >= count ? j - count : j;
         bool hit; float t;
-        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < pb.count);
-        sphere_distance(lds[pb.geom + j], po, pd, &hit, &t);
-        pair_blocked = pair_blocked || (has && i < pb.count && hit && t < pdist);
+        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < count);
+        sphere_distance(lds[geom + j], po, pd, &hit, &t);
+        pair_blocked = pair_blocked || (has && i < count && hit && t < pdist);
     }
     /* the verdicts, back to the rays' lanes (few pairs block) */
     unsigned long long verdicts = __builtin_amdgcn_ballot_w64(pair_blocked);
     while (verdicts != 0ull) {
         const int slot = __ffsll((long long)verdicts) - 1;
         verdicts &= verdicts - 1ull;
-        if (lane == __builtin_amdgcn_readlane(pb.src, slot)) blocked = true;
+        if (lane == (__builtin_amdgcn_readlane(pb.slot, slot) & 63)) blocked = true;
     }
     pb.fill = 0;
     return blocked;
@@ -890,7 +891,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                                          const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
                                          bool *defer) {
     constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3, kPairs = kMode != 0;
-    ShadowPairs pairs = {0, 0, 0, 0};
+    ShadowPairs pairs = {0, 0};
     bool blocked = !active;
     int stat_my_leaves = 0;
     if (p.n_shadow_items == 0) return false;
@@ -988,16 +989,14 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                 if (needers == 0ull) continue;
                 st_wave(st, ST_SHADOW_LEAVES_UNION);
                 if constexpr (kStats) stat_my_leaves += lane_needs ? 1 : 0;
-                if (kPairs && __popcll(needers) < RT_PAIR_DIRECT_LANES) {      /* PAIRS, above */
+                if (kPairs && __popcll(needers) < RT_PAIR_DIRECT_LANES && n < 32) {      /* PAIRS, above */
                     const int wanted = __popcll(needers);
                     if (pairs.fill + wanted > 63) blocked = flush_shadow_pairs<kStats>(lds, pairs, o, d, dist_to_light, blocked, st);
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needers, 0u));
                     /* every lane sends; the ones that do not need the leaf send to lane 63, which is never a slot */
                     const int who = __builtin_amdgcn_ds_permute((lane_needs ? pairs.fill + rank : 63) << 2, lane);
                     const bool fresh = lane >= pairs.fill && lane < pairs.fill + wanted;
-                    pairs.src = fresh ? who : pairs.src;
-                    pairs.geom = fresh ? (int)(bits >> 16) : pairs.geom;
-                    pairs.count = fresh ? n : pairs.count;
+                    pairs.slot = fresh ? (who | (n << 6) | (int)((bits >> 16) << 11)) : pairs.slot;
                     pairs.fill += wanted;
                     continue;
                 }
@@ -1116,7 +1115,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
                                             Stats<kStats> &st, const int wave, const int my_xcc, const int steal) {
     constexpr bool kMayDefer = kMode == 2;
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
-    const int lane = threadIdx.x & 63;
+    const int lane = (int)(threadIdx.x & 63u);
     unsigned long long t_start = 0ull, t_start_real = 0ull;
     const int tile_row = wave / p.tiles_x;                  /* tile number, row-major */
     const int tile_col = wave - tile_row * p.tiles_x;
@@ -1417,7 +1416,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * Two passes (rt_tables.h, "deferred tiles"): pass 0 as above; a tile that defers
      * itself is appended to defer_list.  Pass 1 -- a second launch, after the first has
      * drained -- deals the listed tiles' sub-tiles from one counter. */
-    const int lane = threadIdx.x & 63;
+    const int lane = (int)(threadIdx.x & 63u);
     const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
   if constexpr (kSecondPass) {
     /* second pass: the workgroup renders one deferred tile at a time (DEFERRED tiles, above) */
@@ -1545,6 +1544,16 @@ extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_CLUSTERS)
 rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                           unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                           unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
+    render_body<false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+}
+
+/* the same with the registers of five wavefronts per SIMD, for scenes whose tables leave room for no more than
+ * five workgroups per CU anyway (the 1 024-sphere grid: 31.5 KB): no spills, hence no scratch traffic */
+extern "C" __global__ void __launch_bounds__(256, 5)
+rt_render_kernel_clusters_wide(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
+                               unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                               unsigned int *__restrict__ defer_list) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
