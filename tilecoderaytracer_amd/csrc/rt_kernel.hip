@@ -1571,7 +1571,10 @@ rt_render_kernel_deferring(const RtParams p_in_kernarg, const float4 *__restrict
 }
 
 /* ... and the second pass: the deferred tiles, one per workgroup (of up to 8 wavefronts) at a time */
-extern "C" __global__ void __launch_bounds__(512)
+#ifndef RT_SECOND_MIN_BLOCKS
+#define RT_SECOND_MIN_BLOCKS 1
+#endif
+extern "C" __global__ void __launch_bounds__(512, RT_SECOND_MIN_BLOCKS)
 rt_render_kernel_second(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                         unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                         unsigned int *__restrict__ defer_list) {
