@@ -167,13 +167,14 @@ int rt_strip_bounds(int W, int ngpu, int g, int *x0, int *x1);
  *     a ray: 1-16, 17-32, 33-48, 49-64 (what bounce compaction could merge)
  *   21, 22 nearest-hit scans whose bundle cull was skipped (ray directions of both signs on
  *     every axis), and the cluster box tests issued in them
+ *   23, 24 sphere tests of cluster leaves issued in those scans, and in all nearest-hit scans
  * wave_cycles (may be NULL) receives, per wavefront tile in row-major order
  * (tile = tile_row * tiles_x + tile_col), six words {shader cycles the
  * wavefront was resident, sphere tests it issued, box tests it issued, scans
  * it ran, start and end time on the 100 MHz constant clock}, up to
  * n_wave_cycles words.  out_rgb may be NULL.  The reference has no
  * counterpart (its gprof figures are quoted in SURVEY.md section 3.3). */
-#define RT_STATS_COUNT 23
+#define RT_STATS_COUNT 25
 int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, int x0, int x1,
                     int max_depth, float *out_rgb, uint64_t *stats, int n_stats,
                     uint64_t *wave_cycles, int n_wave_cycles);

@@ -103,6 +103,8 @@ enum {
     ST_NEAREST_49_64,       /* ... with 49-64 */
     ST_NEAREST_UNCULLED,    /* wavefronts: nearest-hit scans whose bundle cull was skipped (directions all over) */
     ST_NEAREST_UNCULLED_BOX,/* wavefronts: cluster box tests issued in those scans */
+    ST_NEAREST_UNCULLED_SPHERE, /* wavefronts: sphere tests issued in those scans */
+    ST_NEAREST_SPHERE,      /* wavefronts: sphere tests issued in all nearest-hit scans */
     ST_COUNT
 };
 template <bool kStats> struct Stats { };
@@ -752,6 +754,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
 #pragma unroll 2
                 for (int i = 0; i < n; ++i) {
                     st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+                    st_wave(st, ST_NEAREST_SPHERE); if (stat_unculled) st_wave(st, ST_NEAREST_UNCULLED_SPHERE);
                     sphere_distance(g[i], o, d, &hit, &t);
                     if (wave_any(hit)) {
                         const int member = (int)ids[i];

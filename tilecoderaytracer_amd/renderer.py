@@ -60,7 +60,7 @@ class Renderer:
                   "cycles_winner", "cycles_lights", "cycles_reflect",
                   "shadow_candidates", "shadow_leaves_union", "shadow_leaves_maxlane",
                   "nearest_scans_1_16", "nearest_scans_17_32", "nearest_scans_33_48", "nearest_scans_49_64",
-                  "nearest_scans_unculled", "nearest_unculled_box_tests")
+                  "nearest_scans_unculled", "nearest_unculled_box_tests", "nearest_unculled_sphere_tests", "nearest_sphere_tests")
 
     def render_stats(self, W, H, max_depth, x0=0, x1=None, wave_cycles=False):
         """Counting build: returns (image, {counter: value}[, per wavefront tile (tiles_z, tiles_x, 6) = cycles, sphere tests, box tests, scans, start, end (100 MHz)])."""
