@@ -566,6 +566,84 @@ __device__ __forceinline__ bool some_ray_needs_most_leaves(const float4 *items, 
     return wave_any(asked >= 2 && 4 * needed >= 3 * asked);
 }
 
+/* NEAREST PAIRS -- the pair compaction of the shadow scans (PAIRS, above in_shade()) for the nearest-hit
+ * scan.  A leaf that fewer than RT_PAIR_DIRECT_LANES lanes need is not tested for the whole wavefront:
+ * the needing lanes push their lane number to the next free slots, the slots note the leaf, and a
+ * flush lets every slot find the nearest member of its leaf for its ray (minimum of (distance, Scene
+ * index)); the results then go back PUSH by push -- within one push every ray has at most one slot, so
+ * the rays' lanes pull theirs (slot = first slot of the push + rank among the needing lanes) and take
+ * the minimum with what they hold.  Same tests, and the minimum does not depend on their order
+ * (src/RayTracer.cpp:71-80).  While pairs wait, `best` is stale (too large): culls by it are weaker,
+ * never wrong; the buffer is flushed from RT_NEAR_FLUSH_PAIRS pairs on to keep them effective. */
+#ifndef RT_NEAR_FLUSH_PAIRS
+#define RT_NEAR_FLUSH_PAIRS 32
+#endif
+#ifndef RT_PAIR_DIRECT_LANES
+#define RT_PAIR_DIRECT_LANES 40      /* a leaf this many lanes need is tested for the whole wavefront at once */
+#endif
+
+/* lane `lane_select` of `vector` := value (both wave-uniform) */
+__device__ __forceinline__ int write_lane(const int value, const int lane_select, const int vector) {
+    return (int)(threadIdx.x & 63u) == lane_select ? value : vector;
+}
+struct NearPairs {
+    int slot;               /* per slot (= lane): the ray's lane | member count << 6 | the leaf's first member quad << 11 */
+    int ids;                /* per slot: u32 index of the leaf's members' Scene indices */
+    int push_lo, push_hi;   /* per push (lane r = push r of this buffer): the lanes that needed its leaf */
+    int fill, pushes;       /* wave-uniform: slots in use, pushes recorded */
+};
+
+__device__ __forceinline__ float lane_pull_f(const int byte_addr, const float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+template <bool kStats>
+__device__ __forceinline__ void flush_near_pairs(const float4 *lds, NearPairs &pb, const V3 o, const V3 d,
+                                                 float *best_io, int *best_idx_io, Stats<kStats> &st) {
+    if (pb.fill == 0) return;
+    const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool has = lane < pb.fill;
+    const int src = pb.slot & 63, count = (pb.slot >> 6) & 31, geom = pb.slot >> 11;
+    const int from = src << 2;
+    const V3 po = mk(lane_pull_f(from, o.x), lane_pull_f(from, o.y), lane_pull_f(from, o.z));
+    const V3 pd = mk(lane_pull_f(from, d.x), lane_pull_f(from, d.y), lane_pull_f(from, d.z));
+    const int rot = count == 16 ? ((geom >> 4) & 15) : 0;
+    float pair_t = 65535.0f;
+    int pair_idx = -1;
+    for (int i = 0; wave_any(has && i < count); ++i) {
+        int j = i + rot;
+        j = j >= count ? j - count : j;
+        bool hit; float t;
+        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < count);
+        st_wave(st, ST_NEAREST_SPHERE);
+        sphere_distance(lds[geom + j], po, pd, &hit, &t);
+        hit = hit && has && i < count;
+        if (wave_any(hit)) {
+            const int member = (int)lds_u32[pb.ids + j];
+            if (hit && nearer(t, member, pair_t, pair_idx)) { pair_t = t; pair_idx = member; }
+        }
+    }
+    /* back to the rays' lanes, push by push */
+    float best = *best_io;
+    int best_idx = *best_idx_io;
+    int first = 0;
+    for (int r = 0; r < pb.pushes; ++r) {
+        const unsigned long long needers = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(pb.push_lo, r) |
+                                           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(pb.push_hi, r) << 32);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needers, 0u));
+        const int theirs = (first + rank) << 2;
+        const float ot = lane_pull_f(theirs, pair_t);
+        const int oi = __builtin_amdgcn_ds_bpermute(theirs, pair_idx);
+        if (((needers >> lane) & 1ull) != 0ull && oi >= 0 && (best_idx < 0 || nearer(ot, oi, best, best_idx))) { best = ot; best_idx = oi; }
+        first += __popcll(needers);
+    }
+    *best_io = best;
+    *best_idx_io = best_idx;
+    pb.fill = 0;
+    pb.pushes = 0;
+}
+
 /* kMode: 0 a first-pass tile of a scene without clustered runs; 4 of a scene with them (PAIRS below); 2 one that may also
  * defer itself; 3 the leader of a second-pass workgroup */
 template <bool kStats, int kMode>
@@ -574,7 +652,8 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                                                   const V3 origins_lo, const V3 origins_hi,
                                                   float *best_out, int *best_idx_out, Stats<kStats> &st,
                                                   bool *defer) {
-    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3;
+    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3, kPairs = kMode != 0;
+    NearPairs pairs = {0, 0, 0, 0, 0, 0};
     float best = 65535.0f;
     int best_idx = -1;
     st_lane(st, ST_NEAREST_RAYS, active);
@@ -749,7 +828,23 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 if (stat_unculled) st_wave(st, ST_NEAREST_UNCULLED_BOX);
                 const bool lane_needs = active && box_needed(i0, i1, o, inv, best);
-                if (!wave_any(lane_needs)) continue;
+                const unsigned long long needers = __builtin_amdgcn_ballot_w64(lane_needs);
+                if (needers == 0ull) continue;
+                if (kPairs && __popcll(needers) < RT_PAIR_DIRECT_LANES && n < 32) {      /* NEAREST PAIRS, above */
+                    const int wanted = __popcll(needers);
+                    if (pairs.fill + wanted > 63 || pairs.pushes == 64) flush_near_pairs<kStats>(lds, pairs, o, d, &best, &best_idx, st);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needers, 0u));
+                    const int who = __builtin_amdgcn_ds_permute((lane_needs ? pairs.fill + rank : 63) << 2, lane);
+                    const bool fresh = lane >= pairs.fill && lane < pairs.fill + wanted;
+                    pairs.slot = fresh ? (who | (n << 6) | (int)((bits >> 16) << 11)) : pairs.slot;
+                    pairs.ids = fresh ? (int)bits1 : pairs.ids;
+                    pairs.push_lo = write_lane((int)(uint32_t)needers, pairs.pushes, pairs.push_lo);
+                    pairs.push_hi = write_lane((int)(uint32_t)(needers >> 32), pairs.pushes, pairs.push_hi);
+                    pairs.fill += wanted;
+                    pairs.pushes += 1;
+                    if (pairs.fill >= RT_NEAR_FLUSH_PAIRS) flush_near_pairs<kStats>(lds, pairs, o, d, &best, &best_idx, st);
+                    continue;
+                }
                 const uint32_t *ids = lds_u32 + bits1;
 #pragma unroll 2
                 for (int i = 0; i < n; ++i) {
@@ -802,6 +897,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             }
         }
     }
+    if constexpr (kPairs) flush_near_pairs<kStats>(lds, pairs, o, d, &best, &best_idx, st);
     *best_out = best;
     *best_idx_out = active ? best_idx : -1;
 }
@@ -851,10 +947,6 @@ struct ShadowPairs {
     int slot;               /* per slot (= lane): the ray's lane | member count << 6 | the leaf's first member quad << 11 */
     int fill;               /* wave-uniform: slots in use */
 };
-
-__device__ __forceinline__ float lane_pull_f(const int byte_addr, const float v) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
-}
 
 template <bool kStats>
 __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPairs &pb, const V3 o, const V3 d,
