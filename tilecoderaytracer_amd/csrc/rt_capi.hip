@@ -689,7 +689,9 @@ int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, i
         if ((double)scene_bytes + levels * per_level > (double)RT_MAX_LDS_BYTES)
             return fail(RT_ERR_CAPACITY, "stack option: tables + bounce stack exceed 160 KiB LDS");
     } else if (s->stack_opt == 0) {
-        const double room = (double)(RT_MAX_LDS_BYTES / RT_STACK_LDS_SHARE) - (double)scene_bytes;
+        /* the clustered-scene kernels run six wavefronts per SIMD (80 registers, no spills), the others seven */
+        const int share = (s->n_clusters > 0 && s->pairs_opt && s->cull_opt) ? 6 : RT_STACK_LDS_SHARE;
+        const double room = (double)(RT_MAX_LDS_BYTES / share) - (double)scene_bytes;
         in_lds = room > 0.0 ? std::floor(room / per_level) : 0.0;
         if (in_lds > levels) in_lds = levels;
     }

@@ -1631,9 +1631,11 @@ rt_render_kernel_large(const RtParams p_in_kernarg, const float4 *__restrict__ i
     render_body<false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
-/* scenes with clustered sphere runs (PAIRS): one more wavefront's worth of registers per lane */
+/* scenes with clustered sphere runs (PAIRS, NEAREST PAIRS): 80 registers, six wavefronts per SIMD -- at 72 the
+ * colour a finished lane holds across the bounce loop was spilled (0.8-1.3 GB of scratch traffic per 256-sphere-grid
+ * frame) for no measurable gain in speed */
 #ifndef RT_WAVES_PER_SIMD_CLUSTERS
-#define RT_WAVES_PER_SIMD_CLUSTERS 7
+#define RT_WAVES_PER_SIMD_CLUSTERS 6
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_CLUSTERS)
 rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
