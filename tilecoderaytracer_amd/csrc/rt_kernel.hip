@@ -23,6 +23,14 @@
  *    from LDS with the same address in every lane (a broadcast).  Before that,
  *    the wavefront culls the table cooperatively: lane i tests item i's box
  *    against a bound of all 64 rays, one ballot yields the candidates.
+ *  - Scenes with clustered sphere runs: the (ray, leaf) pairs that the per-lane
+ *    box tests leave are compacted into full wavefront rounds (PAIRS, NEAREST
+ *    PAIRS); tiles with scans that keep one wavefront busy for milliseconds can
+ *    defer themselves to a second launch in which a whole workgroup shares the
+ *    leaves of every scan (DEFERRED tiles).  The same tests on the same
+ *    operands; nearest = minimum of (distance, Scene index), shadow = OR.
+ *  - One body, several __global__ entry points (bottom of the file); the host
+ *    picks by scene (rt_capi.hip, launch()).
  *
  * Arithmetic contract: IEEE-754 binary32, no FMA contraction
  * (-ffp-contract=off and the pragma below), correctly rounded '/' and sqrtf
@@ -311,9 +319,6 @@ __device__ __forceinline__ int here(int uniform_value) {
 }
 
 __device__ __forceinline__ float uniform_f(const float v) {
-#ifdef RT_NO_UNIFORM
-    return v;
-#endif
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
@@ -321,18 +326,8 @@ __device__ __forceinline__ V3 approx_inverse(const V3 d) {
     return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 }
 
-/* Wavefront-wide min / max of a per-lane value with DPP (no LDS traffic): four
- * butterfly steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror,
- * row mirror), then the four row results are read out as scalars.  Call only
- * where all 64 lanes are active. */
-template <int kCtrl> __device__ __forceinline__ float dpp_f(const float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kCtrl, 0xF, 0xF, false));
-}
-#define RT_DPP_XOR1 0xB1          /* quad_perm:[1,0,3,2] */
-#define RT_DPP_XOR2 0x4E          /* quad_perm:[2,3,0,1] */
-#define RT_DPP_HALF_MIRROR 0x141  /* row_half_mirror     */
-#define RT_DPP_MIRROR 0x140       /* row_mirror          */
-/* Box of a per-lane point over the lanes with `use` set: three minima and three
+/* Wavefront-wide reductions with DPP (no LDS traffic).
+ * Box of a per-lane point over the lanes with `use` set: three minima and three
  * maxima reduced side by side (the six chains fill each other's DPP wait
  * states): four butterfly steps inside each row of 16 lanes, then row_bcast
  * 15 / 31 fold the rows so that lane 63 holds the result.  All 64 lanes must be
@@ -378,28 +373,6 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k) {
     return (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
 }
 
-#ifdef RT_OLD_REDUCTIONS
-__device__ __forceinline__ float wave_min(float v) {
-    v = fminf(v, dpp_f<RT_DPP_XOR1>(v));
-    v = fminf(v, dpp_f<RT_DPP_XOR2>(v));
-    v = fminf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
-    v = fminf(v, dpp_f<RT_DPP_MIRROR>(v));
-    const int i = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
-    return fminf(fminf(r0, r1), fminf(r2, r3));
-}
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_f<RT_DPP_XOR1>(v));
-    v = fmaxf(v, dpp_f<RT_DPP_XOR2>(v));
-    v = fmaxf(v, dpp_f<RT_DPP_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp_f<RT_DPP_MIRROR>(v));
-    const int i = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-#endif
 
 /* getCollision (src/RayTracer.cpp:50-89) over the ITEM table with a
  * wave-cooperative cull -- the nearest-hit counterpart of in_shade() below.
@@ -666,15 +639,9 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
     float dminx = -inf, dmaxx = inf, dminy = -inf, dmaxy = inf, dminz = -inf, dmaxz = inf;
     bool cull = p.cull != 0 && p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
     if (cull) {
-#ifdef RT_OLD_REDUCTIONS
-        dminx = wave_min(active ? d.x : inf); dmaxx = wave_max(active ? d.x : -inf);
-        dminy = wave_min(active ? d.y : inf); dmaxy = wave_max(active ? d.y : -inf);
-        dminz = wave_min(active ? d.z : inf); dmaxz = wave_max(active ? d.z : -inf);
-#else
         V3 dlo, dhi;
         wave_bounds3(d, active, &dlo, &dhi);
         dminx = dlo.x; dminy = dlo.y; dminz = dlo.z; dmaxx = dhi.x; dmaxy = dhi.y; dmaxz = dhi.z;
-#endif
         /* directions all over the place: the cone is everything, skip the cull */
         cull = !((dminx < 0.0f && dmaxx > 0.0f) && (dminy < 0.0f && dmaxy > 0.0f) && (dminz < 0.0f && dmaxz > 0.0f));
         if (!cull) st_wave(st, ST_NEAREST_UNCULLED);
@@ -682,35 +649,19 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
     const bool stat_unculled = !cull && p.cull != 0 && p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS;
     (void)stat_unculled;
     float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
-#ifdef RT_BRANCHY_CULL
-    float rnx = 0, rxx = 0, rny = 0, rxy = 0, rnz = 0, rxz = 0;
-#else
     float lax = 0, hax = 0, lbx = 0, hbx = 0, lay = 0, hay = 0, lby = 0, hby = 0, laz = 0, haz = 0, lbz = 0, hbz = 0;
-#endif
     if (cull) {
         if (have_origin_box) {                 /* the eye for primary rays, else the previous level's shading points */
             ominx = origins_lo.x; ominy = origins_lo.y; ominz = origins_lo.z;
             omaxx = origins_hi.x; omaxy = origins_hi.y; omaxz = origins_hi.z;
         } else {
-#ifdef RT_OLD_REDUCTIONS
-            ominx = wave_min(active ? o.x : inf); omaxx = wave_max(active ? o.x : -inf);
-            ominy = wave_min(active ? o.y : inf); omaxy = wave_max(active ? o.y : -inf);
-            ominz = wave_min(active ? o.z : inf); omaxz = wave_max(active ? o.z : -inf);
-#else
             V3 olo, ohi;
             wave_bounds3(o, active, &olo, &ohi);
             ominx = olo.x; ominy = olo.y; ominz = olo.z; omaxx = ohi.x; omaxy = ohi.y; omaxz = ohi.z;
-#endif
         }
-#ifdef RT_BRANCHY_CULL
-        rnx = uniform_f(__builtin_amdgcn_rcpf(dminx)); rxx = uniform_f(__builtin_amdgcn_rcpf(dmaxx));
-        rny = uniform_f(__builtin_amdgcn_rcpf(dminy)); rxy = uniform_f(__builtin_amdgcn_rcpf(dmaxy));
-        rnz = uniform_f(__builtin_amdgcn_rcpf(dminz)); rxz = uniform_f(__builtin_amdgcn_rcpf(dmaxz));
-#else
         bound_multipliers(dminx, dmaxx, &lax, &hax, &lbx, &hbx);
         bound_multipliers(dminy, dmaxy, &lay, &hay, &lby, &hby);
         bound_multipliers(dminz, dmaxz, &laz, &haz, &lbz, &hbz);
-#endif
     }
     const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
     const float4 *items = lds + p.near_items_off;
@@ -730,25 +681,11 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             const float ex = RT_SPHERE_SLACK * far + 1.0e-4f;
             ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
             /* feasible t: [t_lo, t_hi], starting from [0, 65535 (the reference's infinity) + slack] */
-#ifndef RT_BRANCHY_CULL
             /* t dmin <= b and t dmax >= a per axis, as lower / upper bounds of t through
              * the multipliers of bound_multipliers(); a NaN product is no bound */
             const float t_lo = fmaxf(fmaxf(fmaxf(0.0f, fmaxf(bx * lax, ax * lbx)), fmaxf(by * lay, ay * lby)), fmaxf(bz * laz, az * lbz));
             const float t_hi = fminf(fminf(fminf(65600.0f, fminf(bx * hax, ax * hbx)), fminf(by * hay, ay * hby)), fminf(bz * haz, az * hbz));
             const bool empty = (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi)) || (t_hi < -1.0e-6f);
-#else
-            float t_lo = 0.0f, t_hi = 65600.0f;
-            bool empty = false;
-            /* t*dmin <= b */
-            if (dminx > 0.0f) t_hi = fminf(t_hi, bx * rnx); else if (dminx < 0.0f) t_lo = fmaxf(t_lo, bx * rnx); else empty = empty || (bx < 0.0f);
-            if (dminy > 0.0f) t_hi = fminf(t_hi, by * rny); else if (dminy < 0.0f) t_lo = fmaxf(t_lo, by * rny); else empty = empty || (by < 0.0f);
-            if (dminz > 0.0f) t_hi = fminf(t_hi, bz * rnz); else if (dminz < 0.0f) t_lo = fmaxf(t_lo, bz * rnz); else empty = empty || (bz < 0.0f);
-            /* t*dmax >= a */
-            if (dmaxx > 0.0f) t_lo = fmaxf(t_lo, ax * rxx); else if (dmaxx < 0.0f) t_hi = fminf(t_hi, ax * rxx); else empty = empty || (ax > 0.0f);
-            if (dmaxy > 0.0f) t_lo = fmaxf(t_lo, ay * rxy); else if (dmaxy < 0.0f) t_hi = fminf(t_hi, ay * rxy); else empty = empty || (ay > 0.0f);
-            if (dmaxz > 0.0f) t_lo = fmaxf(t_lo, az * rxz); else if (dmaxz < 0.0f) t_hi = fminf(t_hi, az * rxz); else empty = empty || (az > 0.0f);
-            empty = empty || (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi));
-#endif
             const bool candidate = base + lane < p.n_near_items && !empty;
             mask = __builtin_amdgcn_ballot_w64(candidate);
             if (candidate) key = (__float_as_uint(t_lo) & ~63u) | (uint32_t)lane;      /* t_lo >= 0: its bits order like its value */
@@ -1164,7 +1101,6 @@ __device__ __forceinline__ bool fmod_small_quotient_ok(const float x, const floa
 }
 
 __device__ __forceinline__ int checkerboard_select(const float width, const float height, float x, float y) {
-#ifndef RT_NO_LEAN_FMOD
     /* every lane that is here takes the short route, or none does */
     if (!wave_any(!(fmod_small_quotient_ok(x, width) && fmod_small_quotient_ok(y, height)))) {
         const float rw = __builtin_amdgcn_rcpf(width), rh = __builtin_amdgcn_rcpf(height);
@@ -1173,7 +1109,6 @@ __device__ __forceinline__ int checkerboard_select(const float width, const floa
         if (y >= 0) y = fmod_small_quotient(y, height, rh);
         else        y = fmod_small_quotient(fmod_small_quotient(-y, height, rh) + height / 2.0f, height, rh);
     } else
-#endif
     {
         if (x >= 0) x = fmodf(x, width);
         else        x = fmodf((fmodf((-x), width) + width / 2.0f), width);
@@ -1325,13 +1260,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
             /* box of the shading points, shared by every light's shadow scan */
             have_box = p.cull != 0 && (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS);
             if (have_box) {
-#ifdef RT_OLD_REDUCTIONS
-                const float inf = __builtin_huge_valf();
-                box_lo = mk(wave_min(shade ? P.x : inf), wave_min(shade ? P.y : inf), wave_min(shade ? P.z : inf));
-                box_hi = mk(wave_max(shade ? P.x : -inf), wave_max(shade ? P.y : -inf), wave_max(shade ? P.z : -inf));
-#else
                 wave_bounds3(P, shade, &box_lo, &box_hi);
-#endif
             }
             V3 bundle_centre = mk(0, 0, 0), bundle_half = bundle_centre;
             if (p.cull != 0 && p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
