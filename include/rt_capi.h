@@ -196,7 +196,12 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   size), 0 = automatic (LDS up to 80 KiB)
  *   "grid_mult"     persistent grid = occupancy x CUs x this; 0 = no persistence
  *   "first_row"     where the tile queues start, thousandths of the image
- *                   height (rows wrap around); -1 = automatic
+ *                   height (from there upwards; rows wrap around); -1 = automatic:
+ *                   row 0 upwards, or -- scenes with a horizon and clustered sphere
+ *                   runs -- from a little above the horizon row downwards (tiles in
+ *                   order of decreasing cost)
+ *   "second_block"  threads per workgroup of the second pass ("defer"): 0 = as the
+ *                   first pass, else a multiple of 64 up to 512
  *   "cull"          0 = the plain scans of the reference: every object one item in
  *                   Scene index order, no wavefront-level culling, no
  *                   nearest-first early exit, no sphere clustering, no
