@@ -213,8 +213,8 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   in a second one, where a whole workgroup renders it and its
  *                   wavefronts share the leaves of every scan (so that no
  *                   wavefront is kept for milliseconds by one tile);
- *                   -1 = automatic (on when the launch renders a strip of the image,
- *                   off for whole frames), 0 = never, 65 = every tile that has a candidate
+ *                   -1 = automatic (on when the launch renders a strip of at most a sixth
+ *                   of the image's width, off for wider strips and whole frames), 0 = never, 65 = every tile that has a candidate
  *                   leaf at all (exercises the second pass in tests)
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
  *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */

@@ -765,11 +765,13 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.defer_leaves = 0;
     p.coop_off = 0;
     if (s->n_clusters > 0 && s->cull_opt && !global_tables)
-        /* automatic: only when the launch renders a STRIP of the image (one GPU's share of a frame): there
-         * the strip cannot finish before its longest tile, and the second pass cuts that tile to a quarter;
-         * on a whole frame the heavy tiles are simply handed out first, and the second pass would only
-         * cost its own overhead (measured: +13 % on the 1 024-sphere grid frame) */
-        p.defer_leaves = s->defer_opt == 65 ? -1 : (s->defer_opt >= 0 ? s->defer_opt : ((x1 - x0) < W ? RT_DEFER_LEAVES : 0));
+        /* automatic: only when the launch renders a NARROW strip of the image (a sixth of its width or less:
+         * one GPU's share of a frame on six or more GPUs): there the strip cannot finish before its longest
+         * tile, and the second pass cuts that tile to a quarter.  On a whole frame, or a half or a quarter of
+         * one, the heavy tiles are simply handed out first and the second pass only costs its overhead
+         * (measured on the 1 024-sphere grid: whole frame +13 %, half frame 2.9 -> 4.3 ms, quarter 2.5 -> 2.9 ms,
+         * eighth 2.4 -> 1.9 ms) */
+        p.defer_leaves = s->defer_opt == 65 ? -1 : (s->defer_opt >= 0 ? s->defer_opt : ((long long)(x1 - x0) * 6 <= (long long)W ? RT_DEFER_LEAVES : 0));
     /* the second pass's workgroups: more wavefronts per tile (option "second_block", default: as many as the first pass);
      * only the leader keeps a bounce stack; the cooperation area sits behind tables and stack */
     const int block2 = s->second_block_opt ? s->second_block_opt : block;
