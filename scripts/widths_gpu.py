@@ -3,9 +3,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tilecoderaytracer_amd import HostScene, Renderer
 S = 4096
-for name, d in (("grid32", 4), ("builtin", 4)):
+opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+for name, d in (("grid32", 4), ("grid16", 8)):
     r = Renderer(HostScene.named(name))
-    r.set_option("defer", 0)
+    for k, v in opts.items():
+        r.set_option(k, int(v))
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     for x0, x1 in ((0, 4096), (0, 3072), (0, 2048), (2048, 4096), (1024, 3072), (0, 1024), (1536, 2560), (0, 512)):

@@ -92,6 +92,7 @@ float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 struct EventPair { hipEvent_t start, mid, stop; bool pending, two_passes; };
 constexpr int kEventRing = 64;
+constexpr int RT_DESK_WORDS_HOST = 12;   /* RT_DESK_WORDS of rt_kernel.hip */
 constexpr int kCounterWords = (RT_TILE_QUEUES + 1) * RT_QUEUE_STRIDE;   /* 8 queue heads + the second pass's, own cache lines */
 
 } // namespace
@@ -116,6 +117,7 @@ struct rt_scene {
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
+    int help_opt = 1;             /* clustered scenes: wavefronts out of tiles help their workgroup's long shadow scans (0: they leave) */
     int pairs_opt = 1;            /* scenes with clustered runs: the kernel that compacts (ray, leaf) pairs (0: the plain kernel) */
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int second_block_opt = 0;     /* threads per workgroup of the second pass: 0 = as the first pass, else 64..512 */
@@ -134,6 +136,9 @@ struct rt_scene {
     /* defer list {count, tile, tile, ...} of the launch in flight (launches of one handle are stream-ordered) */
     unsigned int *d_defer = nullptr;
     size_t d_defer_words = 0;
+    /* HELP: 2 KB per workgroup for the rays a wavefront publishes at its workgroup's desk */
+    void *d_help = nullptr;
+    size_t d_help_bytes = 0;
     /* bounce stack in HBM: grid_blocks x (max_depth + 1) x block_threads entries of 16 B */
     void *d_stack = nullptr;
     size_t d_stack_bytes = 0;
@@ -806,6 +811,20 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     }
     /* first-pass kernel: the plain one, the one for clustered scenes (in the register budget that fits the
      * occupancy LDS allows), the large-scene one, or the one whose tiles may defer themselves */
+    /* HELP (rt_kernel.hip): the clustered-scene kernels keep a desk of a few LDS words behind tables and stack */
+    const bool clusters_kernel = !d_stats && !global_tables && p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt;
+    p.desk_off = 0;
+    p.help_rays_quads = 0;
+    if (clusters_kernel && s->help_opt && block > 64) {
+        const int desk_off = p.stack_off + stack_lds_levels * block;
+        const int with_desk = (desk_off + (RT_DESK_WORDS_HOST * 4 + 15) / 16) * 16;
+        if ((size_t)with_desk <= RT_MAX_LDS_BYTES) {
+            p.desk_off = desk_off;
+            p.help_rays_quads = 128;
+            lds_bytes = with_desk;
+            s->launch.lds_bytes = lds_bytes;
+        }
+    }
     const bool clusters_wide = (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
     const void *first = d_stats ? (const void *)rt_render_kernel_stats
                         : global_tables ? (const void *)rt_render_kernel_large
@@ -838,6 +857,15 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
             if (s->d_stack) { HIP_TRY(hipFree(s->d_stack)); s->d_stack = nullptr; s->d_stack_bytes = 0; }
             HIP_TRY(hipMalloc(&s->d_stack, need));
             s->d_stack_bytes = need;
+        }
+    }
+    if (p.help_rays_quads != 0) {
+        const size_t need = (size_t)blocks * (size_t)p.help_rays_quads * 16;
+        if (need > s->d_help_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (s->d_help) { HIP_TRY(hipFree(s->d_help)); s->d_help = nullptr; s->d_help_bytes = 0; }
+            HIP_TRY(hipMalloc(&s->d_help, need));
+            s->d_help_bytes = need;
         }
     }
     const int slot = s->ev_next;
@@ -873,11 +901,11 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     else if (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt && clusters_wide)
         hipLaunchKernelGGL(rt_render_kernel_clusters_wide, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), reinterpret_cast<unsigned int *>(s->d_help));
     else if (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt)
         hipLaunchKernelGGL(rt_render_kernel_clusters, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), reinterpret_cast<unsigned int *>(s->d_help));
     else if (p.defer_leaves != 0)
         hipLaunchKernelGGL(rt_render_kernel_deferring, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
                            p, reinterpret_cast<const float4 *>(s->d_image),
@@ -964,6 +992,7 @@ int rt_scene_destroy(rt_scene *s) {
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_defer) (void)hipFree(s->d_defer);
+    if (s->d_help) (void)hipFree(s->d_help);
     if (s->d_stack) (void)hipFree(s->d_stack);
     delete s;
     return RT_OK;
@@ -1113,6 +1142,10 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "first_row")) {
         if (value < -1 || value > 999) return fail(RT_ERR_INVALID, "first_row is in thousandths of the image height, [0, 999], or -1 (automatic)");
         s->first_row_permille = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "help")) {
+        s->help_opt = value != 0;
         return RT_OK;
     }
     if (!std::strcmp(key, "pairs")) {

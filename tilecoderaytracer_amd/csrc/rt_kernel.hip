@@ -444,6 +444,35 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
 #define RT_COOP_MIN_LEAVES 8     /* fewer candidate leaves than this: the leader tests them itself */
 #endif
 
+/* HELP (clustered scenes, whole frames and wide strips: rt_render_kernel_clusters*).  A wavefront that has run
+ * out of tiles does not leave: it waits at its workgroup's DESK (nine words of LDS) until all the workgroup's
+ * wavefronts are out of tiles, and meanwhile serves the others.  A wavefront whose shadow scan is left with
+ * RT_HELP_MIN_LEAVES or more candidate leaves, and that sees a colleague waiting, publishes its 64 rays (global
+ * memory, 2 KB per workgroup) and the candidate mask at the desk and opens it; everybody -- the owner included --
+ * then takes candidates from a shared cursor, four bits of the mask at a time, and ORs the rays it found blocked
+ * into the desk's verdict.  The owner closes the desk when the cursor is through, waits until the helpers that
+ * are still inside have left, and reads the verdict.  Blocking is an OR over the candidates (src/RayTracer.cpp:
+ * 727-729), so who tests which leaf does not matter.  This is what shortens the END of a frame -- or of a GPU's
+ * strip of it --, when a few tiles with scans over the whole scene are all that is left and most wavefronts
+ * would idle.  Nobody ever waits for a helper to ARRIVE; the owner's wait for helpers to LEAVE is bounded by
+ * one leaf's tests (and by RT_HELP_SPIN_LIMIT, after which the kernel gives up helping for good). */
+enum { RT_DESK_STATE = 0, RT_DESK_CURSOR, RT_DESK_INSIDE, RT_DESK_FINISHED, RT_DESK_MASK_LO, RT_DESK_MASK_HI,
+       RT_DESK_BASE, RT_DESK_VERDICT_LO, RT_DESK_VERDICT_HI, RT_DESK_BROKEN, RT_DESK_WORDS = 12 };
+enum { RT_DESK_FREE = 0, RT_DESK_FILLING = 1, RT_DESK_OPEN = 2, RT_DESK_CLOSING = 3 };
+#ifndef RT_HELP_MIN_LEAVES
+#define RT_HELP_MIN_LEAVES 16
+#endif
+#define RT_HELP_SPIN_LIMIT (1 << 22)
+
+/* the desk's words are read and written with workgroup-scope atomics on the LDS pointer itself (ds_read / ds_write that
+ * the compiler may neither cache nor move); a volatile generic pointer turned them into flat loads */
+__device__ __forceinline__ uint32_t desk_read(uint32_t *desk, const int word) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(desk + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void desk_write(uint32_t *desk, const int word, const uint32_t value) {
+    __hip_atomic_store(desk + word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 /* A share of the candidate leaves of one round of a nearest-hit scan: candidates number
  * share, share + n_shares, ... of leaf_mask (bit i = item base + i), tested for this
  * wavefront's 64 rays; the code of the RT_KIND_SPHERE_LEAF case of nearest_hit_items(). */
@@ -514,6 +543,24 @@ __device__ __forceinline__ bool shadow_leaf_share(const float4 *lds, const float
             sphere_distance(g[i], o, d, &hit, &t);
             blocked = blocked || (hit && t < dist_to_light);
         }
+    }
+    return blocked;
+}
+
+/* HELP: take candidates off the desk's cursor, four mask bits at a time, until it is through */
+template <bool kStats>
+__device__ __forceinline__ bool help_shadow_candidates(const float4 *lds, const float4 *items, uint32_t *desk,
+                                                       const int base, const unsigned long long leaf_mask, bool blocked,
+                                                       const V3 o, const V3 d, const V3 inv, const float dist_to_light,
+                                                       Stats<kStats> &st) {
+    const int lane = (int)(threadIdx.x & 63u);
+    for (;;) {
+        int chunk = 0;
+        if (lane == 0) chunk = (int)atomicAdd(desk + RT_DESK_CURSOR, 1u);
+        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        if (chunk >= 16) break;
+        const unsigned long long part = leaf_mask & (0xFull << (4 * chunk));
+        if (part != 0ull) blocked = shadow_leaf_share<kStats>(lds, items, base, part, 0, 1, blocked, o, d, inv, dist_to_light, st);
     }
     return blocked;
 }
@@ -918,7 +965,7 @@ __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPair
 }
 
 template <bool kStats, int kMode>
-__device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, float4 *wlds, const bool active,
+__device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
                                          const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
                                          bool *defer) {
@@ -971,16 +1018,53 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
-        if ((kLeader || kMayDefer) && p.n_clusters > 0) {
+        if ((kLeader || kMayDefer || kMode == 4) && p.n_clusters > 0) {
             const int plain = min(max(p.shadow_first_leaf - base, 0), 64);
             const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
+            if constexpr (kMode == 4) {                              /* HELP, above near_leaf_share() */
+                uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
+                if (p.help_rays_quads != 0 && __popcll(leaf_mask) >= RT_HELP_MIN_LEAVES && desk_read(desk, RT_DESK_FINISHED) != 0u &&
+                    desk_read(desk, RT_DESK_BROKEN) == 0u) {
+                    int mine = 0;
+                    if (lane == 0) mine = atomicCAS(desk + RT_DESK_STATE, (uint32_t)RT_DESK_FREE, (uint32_t)RT_DESK_FILLING) == (uint32_t)RT_DESK_FREE;
+                    if (__builtin_amdgcn_readfirstlane(mine)) {
+                        float4 *rays = help_rays + (size_t)blockIdx.x * 128;
+                        rays[lane] = make_float4(o.x, o.y, o.z, dist_to_light);
+                        rays[64 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(blocked ? RT_COOP_IDLE : 1u));
+                        __threadfence();
+                        if (lane == 0) {
+                            desk_write(desk, RT_DESK_CURSOR, 0u);
+                            desk_write(desk, RT_DESK_MASK_LO, (uint32_t)leaf_mask);
+                            desk_write(desk, RT_DESK_MASK_HI, (uint32_t)(leaf_mask >> 32));
+                            desk_write(desk, RT_DESK_BASE, (uint32_t)base);
+                            desk_write(desk, RT_DESK_VERDICT_LO, 0u);
+                            desk_write(desk, RT_DESK_VERDICT_HI, 0u);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            desk_write(desk, RT_DESK_STATE, (uint32_t)RT_DESK_OPEN);
+                        }
+                        blocked = help_shadow_candidates<kStats>(lds, items, desk, base, leaf_mask, blocked, o, d, inv, dist_to_light, st);
+                        if (lane == 0) desk_write(desk, RT_DESK_STATE, (uint32_t)RT_DESK_CLOSING);
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      /* CLOSING is out before INSIDE is read */
+                        int spins = 0;
+                        while (desk_read(desk, RT_DESK_INSIDE) != 0u && spins < RT_HELP_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(2); ++spins; }
+                        if (spins >= RT_HELP_SPIN_LIMIT) {
+                            if (lane == 0) desk_write(desk, RT_DESK_BROKEN, 1u);                 /* cannot happen; never hang on it */
+                        }
+                        const unsigned long long verdict = (unsigned long long)desk_read(desk, RT_DESK_VERDICT_LO) |
+                                                           ((unsigned long long)desk_read(desk, RT_DESK_VERDICT_HI) << 32);
+                        blocked = blocked || ((verdict >> lane) & 1ull) != 0ull;
+                        if (lane == 0) desk_write(desk, RT_DESK_STATE, (uint32_t)RT_DESK_FREE);
+                        mask &= ~leaf_mask;
+                    }
+                }
+            }
             if constexpr (kMayDefer) {
                 if (p.defer_leaves < 0 ? leaf_mask != 0ull
                                        : (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves &&
                                           some_ray_needs_most_leaves(items, base, p.n_shadow_items, leaf_mask, !blocked, o, inv, dist_to_light))) {
                     *defer = true; mask = 0ull; base = p.n_shadow_items;    /* ends the scan */
                 }
-            } else if (__popcll(leaf_mask) >= RT_COOP_MIN_LEAVES) {
+            } else if (kLeader && __popcll(leaf_mask) >= RT_COOP_MIN_LEAVES) {
                 /* the workgroup shares these leaves (DEFERRED tiles, above nearest_hit_items()) */
                 mask &= ~leaf_mask;
                 float4 *coop = wlds + p.coop_off;
@@ -1140,7 +1224,8 @@ __device__ __forceinline__ size_t hbm_stack_entry(const RtParams &p, const int l
 /* One wavefront tile: camera rays, the bounce loop, the unwind, the store.  Returns true
  * if the tile deferred itself (kMode 2; nothing is stored then). */
 template <bool kStats, int kMode>
-__device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float *__restrict__ out,
+__device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays,
+                                            float *__restrict__ out,
                                             float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
                                             Stats<kStats> &st, const int wave, const int my_xcc, const int steal) {
     constexpr bool kMayDefer = kMode == 2;
@@ -1272,7 +1357,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
-                const bool blocked = in_shade<kStats, kMode>(p, lds, wlds, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
+                const bool blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
                 if (kMayDefer && defer) { shade = false; alive = false; }
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
@@ -1406,6 +1491,12 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * holds a scene of any size the ABI admits -- no capacity limit, and LDS (hence occupancy)
      * is spent on the bounce stack only. */
     const float4 *lds = kGlobalTables ? image : wlds;
+    /* HELP: the clustered-scene kernels get the workgroups' ray areas where the others get the defer list */
+    constexpr bool kHelp = kClusters && !kMayDefer && !kSecondPass;
+    float4 *help_rays = kHelp ? reinterpret_cast<float4 *>(defer_list) : nullptr;
+    if constexpr (kHelp) {
+        if (p.help_rays_quads != 0 && threadIdx.x < RT_DESK_WORDS) reinterpret_cast<uint32_t *>(wlds + p.desk_off)[threadIdx.x] = 0u;
+    }
     if constexpr (!kGlobalTables) {
         for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) wlds[q] = image[q];
         __syncthreads();
@@ -1455,7 +1546,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             const int pop = __builtin_amdgcn_readfirstlane(next_pop);
             if (pop >= n_deferred) break;
             if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-            (void)render_tile<kStats, 3>(p, lds, wlds, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
+            (void)render_tile<kStats, 3>(p, lds, wlds, nullptr, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
         }
         if (lane == 0) coop[RT_COOP_CMD] = make_float4(__uint_as_float(0u), 0.0f, 0.0f, 0.0f);     /* exit */
         __syncthreads();
@@ -1515,12 +1606,53 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
     if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
-    if (render_tile<kStats, kMayDefer ? 2 : (kClusters ? 4 : 0)>(p, lds, wlds, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
+    if (render_tile<kStats, kMayDefer ? 2 : (kClusters ? 4 : 0)>(p, lds, wlds, help_rays, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
         /* the tile deferred itself: the second pass renders it */
         if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
     }
    }  /* next tile of this queue */
   }   /* next queue */
+    if constexpr (kHelp) {
+        /* HELP: out of tiles -- serve the colleagues until they are, too */
+        if (p.help_rays_quads != 0) {
+            uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
+            const uint32_t n_waves = blockDim.x >> 6;
+            if (lane == 0) atomicAdd(desk + RT_DESK_FINISHED, 1u);
+            for (int spins = 0; spins < RT_HELP_SPIN_LIMIT; ++spins) {
+                if (desk_read(desk, RT_DESK_FINISHED) >= n_waves || desk_read(desk, RT_DESK_BROKEN) != 0u) break;
+                if (desk_read(desk, RT_DESK_STATE) != (uint32_t)RT_DESK_OPEN) { __builtin_amdgcn_s_sleep(8); continue; }
+                if (lane == 0) atomicAdd(desk + RT_DESK_INSIDE, 1u);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");              /* INSIDE is out before the state is read again */
+                if (desk_read(desk, RT_DESK_STATE) == (uint32_t)RT_DESK_OPEN) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const unsigned long long leaf_mask = (unsigned long long)desk_read(desk, RT_DESK_MASK_LO) |
+                                                         ((unsigned long long)desk_read(desk, RT_DESK_MASK_HI) << 32);
+                    const int base = (int)desk_read(desk, RT_DESK_BASE);
+                    const volatile float4 *rays = help_rays + (size_t)blockIdx.x * 128;
+                    const float ox = rays[lane].x, oy = rays[lane].y, oz = rays[lane].z, dist = rays[lane].w;
+                    const float dx = rays[64 + lane].x, dy = rays[64 + lane].y, dz = rays[64 + lane].z;
+                    const uint32_t state = __float_as_uint(rays[64 + lane].w);
+                    const V3 o = mk(ox, oy, oz), d = mk(dx, dy, dz);
+                    const bool blocked = help_shadow_candidates<kStats>(lds, lds + p.shadow_items_off, desk, base, leaf_mask,
+                                                                        state == RT_COOP_IDLE, o, d, approx_inverse(d), dist, st);
+                    const unsigned long long verdict = __builtin_amdgcn_ballot_w64(blocked && state != RT_COOP_IDLE);
+                    if (lane == 0) {
+                        atomicOr(desk + RT_DESK_VERDICT_LO, (uint32_t)verdict);
+                        atomicOr(desk + RT_DESK_VERDICT_HI, (uint32_t)(verdict >> 32));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicSub(desk + RT_DESK_INSIDE, 1u);
+            }
+#ifdef RT_HELP_DEBUG
+            if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0u) {
+                float *dbg = out + 6 * (threadIdx.x >> 6);
+                dbg[0] = (float)desk_read(desk, RT_DESK_FINISHED); dbg[1] = (float)n_waves; dbg[2] = (float)desk_read(desk, RT_DESK_STATE);
+                dbg[3] = (float)desk_read(desk, RT_DESK_INSIDE); dbg[4] = (float)p.desk_off; dbg[5] = (float)desk_read(desk, RT_DESK_BROKEN);
+            }
+#endif
+        }
+    }
   }
     if constexpr (kStats) {
 #pragma unroll

@@ -155,6 +155,9 @@ typedef struct RtParams {
      * tiles one per WORKGROUP: wavefront 0 leads, all wavefronts share the candidate leaves of its scans
      * through the LDS area at quad coop_off (behind the tables and the bounce stack). */
     int32_t defer_leaves, coop_off;
+    /* HELP (rt_kernel.hip): the workgroup's desk, RT_DESK_WORDS words of LDS at quad desk_off; help_rays_quads != 0:
+     * the launch carries 128 quads of global memory per workgroup for the published rays (0: no helping) */
+    int32_t desk_off, help_rays_quads;
     int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
 } RtParams;
 
