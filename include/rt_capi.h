@@ -213,9 +213,18 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   in a second one, where a whole workgroup renders it and its
  *                   wavefronts share the leaves of every scan (so that no
  *                   wavefront is kept for milliseconds by one tile);
- *                   -1 = automatic (on when the launch renders a strip of at most a sixth
- *                   of the image's width, off for wider strips and whole frames), 0 = never, 65 = every tile that has a candidate
- *                   leaf at all (exercises the second pass in tests)
+ *                   -1 = automatic (never while "help" is on; with help off, when the
+ *                   launch renders a strip of at most a sixth of the image's width),
+ *                   0 = never, 65 = every tile that has a candidate leaf at all
+ *                   (exercises the second pass in tests)
+ *   "help"          1 (default) = scenes with clustered sphere runs: a wavefront that
+ *                   has run out of tiles stays and tests candidate leaves of its
+ *                   workgroup's long shadow scans (a desk in LDS, a shared cursor
+ *                   over the candidates; blocking is an OR, so who tests which leaf
+ *                   cannot change a pixel): shortens the end of a frame and, most
+ *                   of all, of a GPU's strip of one; 0 = such wavefronts leave;
+ *                   2..64 = on, and a scan asks for help from this many candidate
+ *                   leaves on (default 8; tests use 2)
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
  *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */
 int rt_set_option(rt_scene *scene, const char *key, int value);

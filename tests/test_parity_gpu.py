@@ -700,6 +700,55 @@ def test_second_pass_inside_a_clustered_sphere_field(oracle):
     assert r.launch_info().deferred_tiles > 0
 
 
+# ------------------------------------------------ round 2: HELP (wavefronts out of tiles serve their workgroup's shadow scans)
+@pytest.mark.parametrize("help_leaves", [2, 5, 16, 64])
+@pytest.mark.parametrize("block", [128, 192, 256])
+@pytest.mark.parametrize("name,W,H,depth", [("grid16", 96, 80, 8), ("grid32", 128, 64, 4), ("grid9", 50, 120, 3)])
+def test_help_does_not_change_results(oracle, name, W, H, depth, block, help_leaves):
+    """rt_set_option("help", n): a shadow scan left with n or more candidate leaves is shared with the workgroup's
+    wavefronts that are out of tiles.  Small images on a grid of one tile per wavefront: every workgroup has idle
+    wavefronts while others still scan.  Same pixels as the oracle, whole image and strip."""
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    r.set_option("help", help_leaves)
+    r.set_option("block_threads", block)
+    r.set_option("defer", 0)
+    for _ in range(2):                            # who helps whom depends on timing: twice
+        assert_same(r.render(W, H, depth), want, f"{name} help {help_leaves}, block {block}")
+    assert_same(r.render(W, H, depth, 5, W - 9), want[5:W - 9], f"{name} help {help_leaves}, block {block}, strip")
+
+
+@pytest.mark.parametrize("seed", [21, 24, 27, 30])
+def test_help_on_adversarial_scenes(oracle, seed):
+    host = _adversarial(HostScene.empty(), seed)
+    orc = _adversarial(oracle.OracleScene(), seed)
+    r = Renderer(host)
+    r.set_option("help", [2, 3, 9, 1][seed % 4])
+    assert_same(r.render(96, 64, 5), orc.render(96, 64, 5), f"adversarial seed {seed}, help")
+
+
+def test_help_on_and_off_render_the_same_strip_of_a_large_frame():
+    """4096^2 frame of the 1 024-sphere grid, the strip of GPU 3 of 8: help on (default), help from 2 leaves on, help off."""
+    imgs = []
+    for value in (1, 2, 0):
+        r = Renderer(HostScene.named("grid32"))
+        r.set_option("help", value)
+        r.set_option("defer", 0)
+        imgs.append(r.render(4096, 4096, 4, 1536, 2048))
+    assert imgs[0].shape == (512, 4096, 3)
+    for img, what in ((imgs[1], "help 2"), (imgs[2], "help off")):
+        assert np.array_equal(imgs[0].view(np.uint32), img.view(np.uint32)), what
+
+
+def test_help_option_range():
+    from tilecoderaytracer_amd import RtError
+    r = Renderer(HostScene.named("grid9"))
+    for bad in (-1, 65):
+        with pytest.raises(RtError):
+            r.set_option("help", bad)
+    assert r.render(16, 16, 2).shape == (16, 16, 3)
+
+
 # ------------------------------------------------ round 2: scenes larger than LDS (tables in global memory)
 def _mixed_scene(scene, n_objects, seed=3):
     """Alternating spheres and finite planes (no runs: nothing clusters, every object is a plain

@@ -770,13 +770,17 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.defer_leaves = 0;
     p.coop_off = 0;
     if (s->n_clusters > 0 && s->cull_opt && !global_tables)
-        /* automatic: only when the launch renders a NARROW strip of the image (a sixth of its width or less:
-         * one GPU's share of a frame on six or more GPUs): there the strip cannot finish before its longest
-         * tile, and the second pass cuts that tile to a quarter.  On a whole frame, or a half or a quarter of
-         * one, the heavy tiles are simply handed out first and the second pass only costs its overhead
-         * (measured on the 1 024-sphere grid: whole frame +13 %, half frame 2.9 -> 4.3 ms, quarter 2.5 -> 2.9 ms,
-         * eighth 2.4 -> 1.9 ms) */
-        p.defer_leaves = s->defer_opt == 65 ? -1 : (s->defer_opt >= 0 ? s->defer_opt : ((long long)(x1 - x0) * 6 <= (long long)W ? RT_DEFER_LEAVES : 0));
+        /* automatic: never while HELP is on (option "help", the default: wavefronts out of tiles serve their
+         * workgroup's long shadow scans inside the one launch; measured on N=8 strips of 4096^2, longest strip:
+         * 1 024-sphere grid 2.66 ms plain, 1.86 ms deferring, 1.78 ms helping; 256-sphere grid d8 1.60 / 1.58 /
+         * 1.23 ms).  With help off: only when the launch renders a NARROW strip of the image (a sixth of its
+         * width or less: one GPU's share of a frame on six or more GPUs): there the strip cannot finish before
+         * its longest tile, and the second pass cuts that tile to a quarter; on a whole frame, or a half or a
+         * quarter of one, the heavy tiles are simply handed out first and the second pass only costs its
+         * overhead (whole frame +13 %, half frame 2.9 -> 4.3 ms, quarter 2.5 -> 2.9 ms, eighth 2.4 -> 1.9 ms) */
+        p.defer_leaves = s->defer_opt == 65 ? -1
+                       : s->defer_opt >= 0 ? s->defer_opt
+                       : (!s->help_opt && (long long)(x1 - x0) * 6 <= (long long)W ? RT_DEFER_LEAVES : 0);
     /* the second pass's workgroups: more wavefronts per tile (option "second_block", default: as many as the first pass);
      * only the leader keeps a bounce stack; the cooperation area sits behind tables and stack */
     const int block2 = s->second_block_opt ? s->second_block_opt : block;
@@ -815,6 +819,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     const bool clusters_kernel = !d_stats && !global_tables && p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt;
     p.desk_off = 0;
     p.help_rays_quads = 0;
+    p.help_leaves = s->help_opt >= 2 ? s->help_opt : RT_HELP_LEAVES;
     if (clusters_kernel && s->help_opt && block > 64) {
         const int desk_off = p.stack_off + stack_lds_levels * block;
         const int with_desk = (desk_off + (RT_DESK_WORDS_HOST * 4 + 15) / 16) * 16;
@@ -1129,7 +1134,10 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
     if (!std::strcmp(key, "block_threads")) {
-        if (value != 0 && (value < 64 || value > 256 || (value % 64) != 0))        /* the kernel's launch bound is 256 */
+#ifndef RT_CLUSTERS_BLOCK
+#define RT_CLUSTERS_BLOCK 256
+#endif
+        if (value != 0 && (value < 64 || value > RT_CLUSTERS_BLOCK || (value % 64) != 0))        /* the kernel's launch bound is 256 */
             return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or 64, 128, 192 or 256");
         s->block_threads_opt = value;
         return RT_OK;
@@ -1145,7 +1153,8 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
     if (!std::strcmp(key, "help")) {
-        s->help_opt = value != 0;
+        if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "help must be 0 (off), 1 (on) or a number of candidate leaves, [2, 64]");
+        s->help_opt = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "pairs")) {

@@ -445,9 +445,9 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
 #endif
 
 /* HELP (clustered scenes, whole frames and wide strips: rt_render_kernel_clusters*).  A wavefront that has run
- * out of tiles does not leave: it waits at its workgroup's DESK (nine words of LDS) until all the workgroup's
+ * out of tiles does not leave: it waits at its workgroup's DESK (ten words of LDS) until all the workgroup's
  * wavefronts are out of tiles, and meanwhile serves the others.  A wavefront whose shadow scan is left with
- * RT_HELP_MIN_LEAVES or more candidate leaves, and that sees a colleague waiting, publishes its 64 rays (global
+ * p.help_leaves or more candidate leaves, and that sees a colleague waiting, publishes its 64 rays (global
  * memory, 2 KB per workgroup) and the candidate mask at the desk and opens it; everybody -- the owner included --
  * then takes candidates from a shared cursor, four bits of the mask at a time, and ORs the rays it found blocked
  * into the desk's verdict.  The owner closes the desk when the cursor is through, waits until the helpers that
@@ -459,9 +459,6 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
 enum { RT_DESK_STATE = 0, RT_DESK_CURSOR, RT_DESK_INSIDE, RT_DESK_FINISHED, RT_DESK_MASK_LO, RT_DESK_MASK_HI,
        RT_DESK_BASE, RT_DESK_VERDICT_LO, RT_DESK_VERDICT_HI, RT_DESK_BROKEN, RT_DESK_WORDS = 12 };
 enum { RT_DESK_FREE = 0, RT_DESK_FILLING = 1, RT_DESK_OPEN = 2, RT_DESK_CLOSING = 3 };
-#ifndef RT_HELP_MIN_LEAVES
-#define RT_HELP_MIN_LEAVES 16
-#endif
 #define RT_HELP_SPIN_LIMIT (1 << 22)
 
 /* the desk's words are read and written with workgroup-scope atomics on the LDS pointer itself (ds_read / ds_write that
@@ -1023,7 +1020,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
             if constexpr (kMode == 4) {                              /* HELP, above near_leaf_share() */
                 uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
-                if (p.help_rays_quads != 0 && __popcll(leaf_mask) >= RT_HELP_MIN_LEAVES && desk_read(desk, RT_DESK_FINISHED) != 0u &&
+                if (p.help_rays_quads != 0 && __popcll(leaf_mask) >= p.help_leaves && desk_read(desk, RT_DESK_FINISHED) != 0u &&
                     desk_read(desk, RT_DESK_BROKEN) == 0u) {
                     int mine = 0;
                     if (lane == 0) mine = atomicCAS(desk + RT_DESK_STATE, (uint32_t)RT_DESK_FREE, (uint32_t)RT_DESK_FILLING) == (uint32_t)RT_DESK_FREE;
@@ -1644,13 +1641,6 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) atomicSub(desk + RT_DESK_INSIDE, 1u);
             }
-#ifdef RT_HELP_DEBUG
-            if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0u) {
-                float *dbg = out + 6 * (threadIdx.x >> 6);
-                dbg[0] = (float)desk_read(desk, RT_DESK_FINISHED); dbg[1] = (float)n_waves; dbg[2] = (float)desk_read(desk, RT_DESK_STATE);
-                dbg[3] = (float)desk_read(desk, RT_DESK_INSIDE); dbg[4] = (float)p.desk_off; dbg[5] = (float)desk_read(desk, RT_DESK_BROKEN);
-            }
-#endif
         }
     }
   }
@@ -1698,7 +1688,10 @@ rt_render_kernel_large(const RtParams p_in_kernarg, const float4 *__restrict__ i
 #ifndef RT_WAVES_PER_SIMD_CLUSTERS
 #define RT_WAVES_PER_SIMD_CLUSTERS 6
 #endif
-extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_CLUSTERS)
+#ifndef RT_CLUSTERS_BLOCK
+#define RT_CLUSTERS_BLOCK 256
+#endif
+extern "C" __global__ void __launch_bounds__(RT_CLUSTERS_BLOCK, RT_WAVES_PER_SIMD_CLUSTERS)
 rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                           unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                           unsigned int *__restrict__ defer_list) {
@@ -1708,7 +1701,7 @@ rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict_
 
 /* the same with the registers of five wavefronts per SIMD, for scenes whose tables leave room for no more than
  * five workgroups per CU anyway (the 1 024-sphere grid: 31.5 KB): no spills, hence no scratch traffic */
-extern "C" __global__ void __launch_bounds__(256, 5)
+extern "C" __global__ void __launch_bounds__(RT_CLUSTERS_BLOCK, 5)
 rt_render_kernel_clusters_wide(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                                unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                                unsigned int *__restrict__ defer_list) {

@@ -110,6 +110,7 @@
 #endif
 #define RT_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)   /* s_getreg_b32 HW_REG_XCC_ID, bits [3:0] */
 
+#define RT_HELP_LEAVES 8
 #ifndef RT_DEFER_LEAVES
 #define RT_DEFER_LEAVES 32           /* automatic: a scan with this many candidate leaves, most of them needed by some ray, defers its tile */
 #endif
@@ -158,6 +159,7 @@ typedef struct RtParams {
     /* HELP (rt_kernel.hip): the workgroup's desk, RT_DESK_WORDS words of LDS at quad desk_off; help_rays_quads != 0:
      * the launch carries 128 quads of global memory per workgroup for the published rays (0: no helping) */
     int32_t desk_off, help_rays_quads;
+    int32_t help_leaves;                 /* a shadow scan with this many candidate leaves asks for help (RT_HELP_LEAVES; option "help") */
     int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
 } RtParams;
 
