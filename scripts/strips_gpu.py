@@ -6,7 +6,7 @@ from tilecoderaytracer_amd import HostScene, Renderer
 from tilecoderaytracer_amd.distributed import strip_bounds
 import torch
 S = 4096
-for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8)]:
+for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8), ("grid32-noshadow", 4)]:
     r = Renderer(HostScene.named(name))
     for a in sys.argv[1:]:
         if "=" in a:

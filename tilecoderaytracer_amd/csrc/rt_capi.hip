@@ -1134,10 +1134,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
     if (!std::strcmp(key, "block_threads")) {
-#ifndef RT_CLUSTERS_BLOCK
-#define RT_CLUSTERS_BLOCK 256
-#endif
-        if (value != 0 && (value < 64 || value > RT_CLUSTERS_BLOCK || (value % 64) != 0))        /* the kernel's launch bound is 256 */
+        if (value != 0 && (value < 64 || value > 256 || (value % 64) != 0))        /* the kernel's launch bound is 256 */
             return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or 64, 128, 192 or 256");
         s->block_threads_opt = value;
         return RT_OK;

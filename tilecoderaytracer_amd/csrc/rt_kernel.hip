@@ -562,6 +562,34 @@ __device__ __forceinline__ bool help_shadow_candidates(const float4 *lds, const 
     return blocked;
 }
 
+/* HELP: one visit to the open desk: take candidates of the owner's scan until the cursor is through */
+template <bool kStats>
+__device__ __forceinline__ void serve_desk(const RtParams &p, const float4 *lds, uint32_t *desk, const float4 *help_rays, Stats<kStats> &st) {
+    const int lane = (int)(threadIdx.x & 63u);
+    if (lane == 0) atomicAdd(desk + RT_DESK_INSIDE, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");                      /* INSIDE is out before the state is read again */
+    if (desk_read(desk, RT_DESK_STATE) == (uint32_t)RT_DESK_OPEN) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const unsigned long long leaf_mask = (unsigned long long)desk_read(desk, RT_DESK_MASK_LO) |
+                                             ((unsigned long long)desk_read(desk, RT_DESK_MASK_HI) << 32);
+        const int base = (int)desk_read(desk, RT_DESK_BASE);
+        const volatile float4 *rays = help_rays + (size_t)blockIdx.x * 128;
+        const float ox = rays[lane].x, oy = rays[lane].y, oz = rays[lane].z, dist = rays[lane].w;
+        const float dx = rays[64 + lane].x, dy = rays[64 + lane].y, dz = rays[64 + lane].z;
+        const uint32_t state = __float_as_uint(rays[64 + lane].w);
+        const V3 o = mk(ox, oy, oz), d = mk(dx, dy, dz);
+        const bool blocked = help_shadow_candidates<kStats>(lds, lds + p.shadow_items_off, desk, base, leaf_mask,
+                                                            state == RT_COOP_IDLE, o, d, approx_inverse(d), dist, st);
+        const unsigned long long verdict = __builtin_amdgcn_ballot_w64(blocked && state != RT_COOP_IDLE);
+        if (lane == 0 && verdict != 0ull) {
+            atomicOr(desk + RT_DESK_VERDICT_LO, (uint32_t)verdict);
+            atomicOr(desk + RT_DESK_VERDICT_HI, (uint32_t)(verdict >> 32));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicSub(desk + RT_DESK_INSIDE, 1u);
+}
+
 /* First-pass tiles: does some ray of the wavefront need most of the candidate leaves of
  * this round?  Every lane asks about four of them (lane, lane + 16, ... : four box tests
  * for the wavefront); a ray that needs three out of four of the candidates it asked
@@ -1618,28 +1646,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             for (int spins = 0; spins < RT_HELP_SPIN_LIMIT; ++spins) {
                 if (desk_read(desk, RT_DESK_FINISHED) >= n_waves || desk_read(desk, RT_DESK_BROKEN) != 0u) break;
                 if (desk_read(desk, RT_DESK_STATE) != (uint32_t)RT_DESK_OPEN) { __builtin_amdgcn_s_sleep(8); continue; }
-                if (lane == 0) atomicAdd(desk + RT_DESK_INSIDE, 1u);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");              /* INSIDE is out before the state is read again */
-                if (desk_read(desk, RT_DESK_STATE) == (uint32_t)RT_DESK_OPEN) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const unsigned long long leaf_mask = (unsigned long long)desk_read(desk, RT_DESK_MASK_LO) |
-                                                         ((unsigned long long)desk_read(desk, RT_DESK_MASK_HI) << 32);
-                    const int base = (int)desk_read(desk, RT_DESK_BASE);
-                    const volatile float4 *rays = help_rays + (size_t)blockIdx.x * 128;
-                    const float ox = rays[lane].x, oy = rays[lane].y, oz = rays[lane].z, dist = rays[lane].w;
-                    const float dx = rays[64 + lane].x, dy = rays[64 + lane].y, dz = rays[64 + lane].z;
-                    const uint32_t state = __float_as_uint(rays[64 + lane].w);
-                    const V3 o = mk(ox, oy, oz), d = mk(dx, dy, dz);
-                    const bool blocked = help_shadow_candidates<kStats>(lds, lds + p.shadow_items_off, desk, base, leaf_mask,
-                                                                        state == RT_COOP_IDLE, o, d, approx_inverse(d), dist, st);
-                    const unsigned long long verdict = __builtin_amdgcn_ballot_w64(blocked && state != RT_COOP_IDLE);
-                    if (lane == 0) {
-                        atomicOr(desk + RT_DESK_VERDICT_LO, (uint32_t)verdict);
-                        atomicOr(desk + RT_DESK_VERDICT_HI, (uint32_t)(verdict >> 32));
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) atomicSub(desk + RT_DESK_INSIDE, 1u);
+                serve_desk<kStats>(p, lds, desk, help_rays, st);
             }
         }
     }
@@ -1688,10 +1695,7 @@ rt_render_kernel_large(const RtParams p_in_kernarg, const float4 *__restrict__ i
 #ifndef RT_WAVES_PER_SIMD_CLUSTERS
 #define RT_WAVES_PER_SIMD_CLUSTERS 6
 #endif
-#ifndef RT_CLUSTERS_BLOCK
-#define RT_CLUSTERS_BLOCK 256
-#endif
-extern "C" __global__ void __launch_bounds__(RT_CLUSTERS_BLOCK, RT_WAVES_PER_SIMD_CLUSTERS)
+extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_CLUSTERS)
 rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                           unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                           unsigned int *__restrict__ defer_list) {
@@ -1701,7 +1705,7 @@ rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict_
 
 /* the same with the registers of five wavefronts per SIMD, for scenes whose tables leave room for no more than
  * five workgroups per CU anyway (the 1 024-sphere grid: 31.5 KB): no spills, hence no scratch traffic */
-extern "C" __global__ void __launch_bounds__(RT_CLUSTERS_BLOCK, 5)
+extern "C" __global__ void __launch_bounds__(256, 5)
 rt_render_kernel_clusters_wide(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                                unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                                unsigned int *__restrict__ defer_list) {
