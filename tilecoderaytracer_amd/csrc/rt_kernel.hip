@@ -1620,8 +1620,12 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
    for (;;) {
     const int pop = __builtin_amdgcn_readfirstlane(next_pop);
     if (pop >= queue_len) break;
-    /* ask for the following tile now; the answer is only needed after this one is rendered */
-    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+    /* ask for the following tile now; the answer is only needed after this one is rendered.  Not so in scenes
+     * with clustered sphere runs, whose tiles take from tens of microseconds to milliseconds: a tile asked for
+     * ahead of a long one waits for it while other wavefronts idle (a strip's timeline showed tiles STARTING a
+     * millisecond after the queues had run dry); there the next tile is asked for when this one is done */
+    const bool ask_ahead = !(kClusters || kMayDefer || kStats) || p.n_clusters == 0;     /* the plain kernels: always */
+    if (ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
     const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
     const int queued_row = macro / p.tiles_x;
     const int tile_col = macro - queued_row * p.tiles_x;
@@ -1629,12 +1633,16 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const int shifted_row = p.rows_downwards ? p.first_macro_row - queued_row : p.first_macro_row + queued_row;
     const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : (shifted_row < 0 ? shifted_row + macro_rows : shifted_row);
     const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
-    if (tile_row >= p.tiles_z) continue;                    /* ragged top macro row */
+    if (tile_row >= p.tiles_z) {                            /* ragged top macro row */
+        if (!ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
+        continue;
+    }
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
     if (render_tile<kStats, kMayDefer ? 2 : (kClusters ? 4 : 0)>(p, lds, wlds, help_rays, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
         /* the tile deferred itself: the second pass renders it */
         if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
     }
+    if (!ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
    }  /* next tile of this queue */
   }   /* next queue */
     if constexpr (kHelp) {
