@@ -165,6 +165,59 @@ __device__ __forceinline__ void sphere_distance(const float4 s, const V3 o, cons
     }
 }
 
+/* The members of a leaf of a clustered sphere run against a shadow segment: does any of them block?  The tests
+ * are sphere_distance()'s, RT_MEMBERS_ABREAST of them side by side: they depend on nothing but the ray, so their
+ * dependency chains (LDS read, ~20 dependent operations, the square root's sequence) overlap instead of queueing
+ * up -- a wavefront that scans the whole field for all of its rays (the horizon tiles) is bound by exactly that
+ * chain.  Blocking is an OR, so the grouping cannot change the result. */
+#ifndef RT_MEMBERS_ABREAST
+#define RT_MEMBERS_ABREAST 4
+#endif
+/* four sphere tests side by side: does any of the valid ones block the segment? */
+__device__ __forceinline__ bool four_spheres_block(const float4 s0, const float4 s1, const float4 s2, const float4 s3,
+                                                   const V3 o, const V3 d, const float dist_to_light,
+                                                   const bool k0, const bool k1, const bool k2, const bool k3) {
+    const V3 e0 = mk(s0.x - o.x, s0.y - o.y, s0.z - o.z), e1 = mk(s1.x - o.x, s1.y - o.y, s1.z - o.z);
+    const V3 e2 = mk(s2.x - o.x, s2.y - o.y, s2.z - o.z), e3 = mk(s3.x - o.x, s3.y - o.y, s3.z - o.z);
+    const float v0 = dot3(e0, d), v1 = dot3(e1, d), v2 = dot3(e2, d), v3 = dot3(e3, d);
+    const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);
+    const float q2 = s2.w - (dot3(e2, e2) - v2 * v2), q3 = s3.w - (dot3(e3, e3) - v3 * v3);
+    /* `if (v < 0) return NULL; ... if (d_squared < 1E-9) return NULL;`, as in sphere_distance() */
+    const bool c0 = k0 && !(v0 < (float)0) && !(q0 < (float)1E-9), c1 = k1 && !(v1 < (float)0) && !(q1 < (float)1E-9);
+    const bool c2 = k2 && !(v2 < (float)0) && !(q2 < (float)1E-9), c3 = k3 && !(v3 < (float)0) && !(q3 < (float)1E-9);
+    bool any = false;
+    if (wave_any(c0 || c1 || c2 || c3)) {
+        const float r0 = sqrtf(q0), r1 = sqrtf(q1), r2 = sqrtf(q2), r3 = sqrtf(q3);
+        const float a0 = v0 - r0, b0 = v0 + r0, a1 = v1 - r1, b1 = v1 + r1, a2 = v2 - r2, b2 = v2 + r2, a3 = v3 - r3, b3 = v3 + r3;
+        const bool h0 = c0 && (b0 > (float)0) && ((a0 < (float)0) ? (b0 < 65535.0f) : (a0 < 65535.0f)) && a0 < dist_to_light;
+        const bool h1 = c1 && (b1 > (float)0) && ((a1 < (float)0) ? (b1 < 65535.0f) : (a1 < 65535.0f)) && a1 < dist_to_light;
+        const bool h2 = c2 && (b2 > (float)0) && ((a2 < (float)0) ? (b2 < 65535.0f) : (a2 < 65535.0f)) && a2 < dist_to_light;
+        const bool h3 = c3 && (b3 > (float)0) && ((a3 < (float)0) ? (b3 < 65535.0f) : (a3 < 65535.0f)) && a3 < dist_to_light;
+        any = h0 || h1 || h2 || h3;
+    }
+    return any;
+}
+
+template <bool kStats, bool kAbreast>
+__device__ __forceinline__ bool leaf_members_block(const float4 *g, const int n, const V3 o, const V3 d, const float dist_to_light,
+                                                   const bool lane_needs, bool blocked, Stats<kStats> &st) {
+    int i = 0;
+    if constexpr (kAbreast && RT_MEMBERS_ABREAST == 4) {      /* not in the plain kernel: its 72 registers do not hold four tests */
+        for (; i + 4 <= n; i += 4) {
+            if constexpr (kStats) { for (int k = 0; k < 4; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs); } }
+            blocked = blocked || four_spheres_block(g[i], g[i + 1], g[i + 2], g[i + 3], o, d, dist_to_light, true, true, true, true);
+        }
+    }
+#pragma unroll 2
+    for (; i < n; ++i) {
+        bool hit; float t;
+        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
+        sphere_distance(g[i], o, d, &hit, &t);
+        blocked = blocked || (hit && t < dist_to_light);
+    }
+    return blocked;
+}
+
 /* Plane prefilter shared by both plane kinds.  t = numerator / denom is only
  * worth computing when it can matter; both skips are exact:
  *  (1) unless numerator and denom are non-zero with equal signs, t <= 0 (or
@@ -533,13 +586,7 @@ __device__ __forceinline__ bool shadow_leaf_share(const float4 *lds, const float
         const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
         if (!wave_any(lane_needs)) continue;
         st_wave(st, ST_SHADOW_LEAVES_UNION);
-#pragma unroll 2
-        for (int i = 0; i < n; ++i) {
-            bool hit; float t;
-            st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
-            sphere_distance(g[i], o, d, &hit, &t);
-            blocked = blocked || (hit && t < dist_to_light);
-        }
+        blocked = leaf_members_block<kStats, true>(g, n, o, d, dist_to_light, lane_needs, blocked, st);
     }
     return blocked;
 }
@@ -689,8 +736,8 @@ __device__ __forceinline__ void flush_near_pairs(const float4 *lds, NearPairs &p
     pb.pushes = 0;
 }
 
-/* kMode: 0 a first-pass tile of a scene without clustered runs; 4 of a scene with them (PAIRS below); 2 one that may also
- * defer itself; 3 the leader of a second-pass workgroup */
+/* kMode: 0 a first-pass tile of a scene without clustered runs; 4 of a scene with them (PAIRS below), 5 the same in the
+ * kernel with the larger register budget; 2 one that may also defer itself; 3 the leader of a second-pass workgroup */
 template <bool kStats, int kMode>
 __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, float4 *wlds, const bool active,
                                                   const V3 o, const V3 d, const bool have_origin_box,
@@ -957,7 +1004,7 @@ struct ShadowPairs {
     int fill;               /* wave-uniform: slots in use */
 };
 
-template <bool kStats>
+template <bool kStats, bool kAbreast>
 __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPairs &pb, const V3 o, const V3 d,
                                                    const float dist_to_light, bool blocked, Stats<kStats> &st) {
     if (pb.fill == 0) return blocked;
@@ -970,13 +1017,26 @@ __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPair
     const float pdist = lane_pull_f(from, dist_to_light);
     const int rot = count == 16 ? ((geom >> 4) & 15) : 0;
     bool pair_blocked = false;
-    for (int i = 0; wave_any(has && i < count); ++i) {
-        int j = i + rot;
-        j = j >= count ? j - count : j;
-        bool hit; float t;
-        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < count);
-        sphere_distance(lds[geom + j], po, pd, &hit, &t);
-        pair_blocked = pair_blocked || (has && i < count && hit && t < pdist);
+    if constexpr (kAbreast && RT_MEMBERS_ABREAST == 4) {     /* four members side by side (leaf_members_block()), where the registers allow */
+        for (int i = 0; wave_any(has && i < count); i += 4) {
+            int j0 = i + rot, j1 = i + 1 + rot, j2 = i + 2 + rot, j3 = i + 3 + rot;
+            j0 = j0 >= count ? j0 - count : j0; j1 = j1 >= count ? j1 - count : j1;
+            j2 = j2 >= count ? j2 - count : j2; j3 = j3 >= count ? j3 - count : j3;
+            const bool k0 = has && i < count, k1 = has && i + 1 < count, k2 = has && i + 2 < count, k3 = has && i + 3 < count;
+            if constexpr (kStats) { for (int k = 0; k < 4; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i + k < count); } }
+            /* a member index past the leaf's end (k false) reads the leaf's first member instead: any valid quad will do */
+            pair_blocked = pair_blocked || four_spheres_block(lds[geom + (k0 ? j0 : 0)], lds[geom + (k1 ? j1 : 0)], lds[geom + (k2 ? j2 : 0)],
+                                                              lds[geom + (k3 ? j3 : 0)], po, pd, pdist, k0, k1, k2, k3);
+        }
+    } else {
+        for (int i = 0; wave_any(has && i < count); ++i) {
+            int j = i + rot;
+            j = j >= count ? j - count : j;
+            bool hit; float t;
+            st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < count);
+            sphere_distance(lds[geom + j], po, pd, &hit, &t);
+            pair_blocked = pair_blocked || (has && i < count && hit && t < pdist);
+        }
     }
     /* the verdicts, back to the rays' lanes (few pairs block) */
     unsigned long long verdicts = __builtin_amdgcn_ballot_w64(pair_blocked);
@@ -995,6 +1055,8 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                                          const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
                                          bool *defer) {
     constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3, kPairs = kMode != 0;
+    constexpr bool kHelped = kMode == 4 || kMode == 5;      /* a first-pass tile of a clustered scene: HELP */
+    constexpr bool kRoomy = kMode == 5 || kMode == 3;       /* kernels with registers to spare: the pair flush tests four members abreast */
     ShadowPairs pairs = {0, 0};
     bool blocked = !active;
     int stat_my_leaves = 0;
@@ -1043,10 +1105,10 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
-        if ((kLeader || kMayDefer || kMode == 4) && p.n_clusters > 0) {
+        if ((kLeader || kMayDefer || kHelped) && p.n_clusters > 0) {
             const int plain = min(max(p.shadow_first_leaf - base, 0), 64);
             const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
-            if constexpr (kMode == 4) {                              /* HELP, above near_leaf_share() */
+            if constexpr (kHelped) {                                 /* HELP, above near_leaf_share() */
                 uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
                 if (p.help_rays_quads != 0 && __popcll(leaf_mask) >= p.help_leaves && desk_read(desk, RT_DESK_FINISHED) != 0u &&
                     desk_read(desk, RT_DESK_BROKEN) == 0u) {
@@ -1132,7 +1194,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                 if constexpr (kStats) stat_my_leaves += lane_needs ? 1 : 0;
                 if (kPairs && __popcll(needers) < RT_PAIR_DIRECT_LANES && n < 32) {      /* PAIRS, above */
                     const int wanted = __popcll(needers);
-                    if (pairs.fill + wanted > 63) blocked = flush_shadow_pairs<kStats>(lds, pairs, o, d, dist_to_light, blocked, st);
+                    if (pairs.fill + wanted > 63) blocked = flush_shadow_pairs<kStats, kRoomy>(lds, pairs, o, d, dist_to_light, blocked, st);
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needers, 0u));
                     /* every lane sends; the ones that do not need the leaf send to lane 63, which is never a slot */
                     const int who = __builtin_amdgcn_ds_permute((lane_needs ? pairs.fill + rank : 63) << 2, lane);
@@ -1141,12 +1203,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                     pairs.fill += wanted;
                     continue;
                 }
-#pragma unroll 2
-                for (int i = 0; i < n; ++i) {
-                    st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
-                    sphere_distance(g[i], o, d, &hit, &t);
-                    blocked = blocked || (hit && t < dist_to_light);
-                }
+                blocked = leaf_members_block<kStats, kPairs>(g, n, o, d, dist_to_light, lane_needs, blocked, st);
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves of a clustered run */
                 const int n_leaves = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
@@ -1185,7 +1242,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
         }
     }
     st_maxlane(st, ST_SHADOW_LEAVES_MAXLANE, stat_my_leaves);
-    if constexpr (kPairs) blocked = flush_shadow_pairs<kStats>(lds, pairs, o, d, dist_to_light, blocked, st);
+    if constexpr (kPairs) blocked = flush_shadow_pairs<kStats, kRoomy>(lds, pairs, o, d, dist_to_light, blocked, st);
     return blocked;
 }
 
@@ -1496,7 +1553,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
     return defer;
 }
 
-template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false, bool kClusters = false>
+template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false, bool kClusters = false, bool kRoomy = false>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack,
@@ -1638,7 +1695,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         continue;
     }
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
-    if (render_tile<kStats, kMayDefer ? 2 : (kClusters ? 4 : 0)>(p, lds, wlds, help_rays, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
+    if (render_tile<kStats, kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
         /* the tile deferred itself: the second pass renders it */
         if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
     }
@@ -1718,7 +1775,7 @@ rt_render_kernel_clusters_wide(const RtParams p_in_kernarg, const float4 *__rest
                                unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                                unsigned int *__restrict__ defer_list) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+    render_body<false, false, false, false, true, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 
 /* the first pass for scenes whose tiles may defer themselves (clustered sphere runs) ... */
