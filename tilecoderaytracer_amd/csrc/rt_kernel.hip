@@ -671,7 +671,7 @@ __device__ __forceinline__ bool some_ray_needs_most_leaves(const float4 *items, 
 #define RT_NEAR_FLUSH_PAIRS 32
 #endif
 #ifndef RT_PAIR_DIRECT_LANES
-#define RT_PAIR_DIRECT_LANES 40      /* a leaf this many lanes need is tested for the whole wavefront at once */
+#define RT_PAIR_DIRECT_LANES 32      /* a leaf this many lanes need is tested for the whole wavefront at once (16 / 24 / 32 / 40: 5.24 / 5.26 / 5.24 / 5.31 ms on grid-32 with four members abreast) */
 #endif
 
 /* lane `lane_select` of `vector` := value (both wave-uniform) */
@@ -997,7 +997,7 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
  * verdicts go back to the rays' lanes.  The same sphere test on the same operands as the direct
  * route, and blocking is an OR, so the result is the reference's (src/RayTracer.cpp:727-729). */
 #ifndef RT_PAIR_DIRECT_LANES
-#define RT_PAIR_DIRECT_LANES 40
+#define RT_PAIR_DIRECT_LANES 32
 #endif
 struct ShadowPairs {
     int slot;               /* per slot (= lane): the ray's lane | member count << 6 | the leaf's first member quad << 11 */
