@@ -999,6 +999,9 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
 #ifndef RT_PAIR_DIRECT_LANES
 #define RT_PAIR_DIRECT_LANES 32
 #endif
+#ifndef RT_LEAVES_ABREAST
+#define RT_LEAVES_ABREAST 1           /* shadow scans: the box tests of two consecutive candidate leaves side by side (grid-32 5.14 -> 4.99 ms) */
+#endif
 struct ShadowPairs {
     int slot;               /* per slot (= lane): the ray's lane | member count << 6 | the leaf's first member quad << 11 */
     int fill;               /* wave-uniform: slots in use */
@@ -1185,25 +1188,47 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                 sphere_distance(g[0], o, d, &hit, &t);
                 blocked = blocked || (hit && t < dist_to_light);
             } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run */
-                const int n = (int)((bits >> 8) & 255u);
+                /* one leaf whose box test is done: its (ray, leaf) pairs into the buffer, or its members for the whole wavefront */
+                auto take_leaf = [&](const uint32_t leaf_bits, const bool lane_needs, const unsigned long long needers) {
+                    const int n = (int)((leaf_bits >> 8) & 255u);
+                    st_wave(st, ST_SHADOW_LEAVES_UNION);
+                    if constexpr (kStats) stat_my_leaves += lane_needs ? 1 : 0;
+                    if (kPairs && __popcll(needers) < RT_PAIR_DIRECT_LANES && n < 32) {      /* PAIRS, above */
+                        const int wanted = __popcll(needers);
+                        if (pairs.fill + wanted > 63) blocked = flush_shadow_pairs<kStats, kRoomy>(lds, pairs, o, d, dist_to_light, blocked, st);
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needers, 0u));
+                        /* every lane sends; the ones that do not need the leaf send to lane 63, which is never a slot */
+                        const int who = __builtin_amdgcn_ds_permute((lane_needs ? pairs.fill + rank : 63) << 2, lane);
+                        const bool fresh = lane >= pairs.fill && lane < pairs.fill + wanted;
+                        pairs.slot = fresh ? (who | (n << 6) | (int)((leaf_bits >> 16) << 11)) : pairs.slot;
+                        pairs.fill += wanted;
+                        return;
+                    }
+                    blocked = leaf_members_block<kStats, kPairs>(lds + (leaf_bits >> 16), n, o, d, dist_to_light, lane_needs, blocked, st);
+                };
+#if RT_LEAVES_ABREAST
+                const int item2 = mask != 0ull ? base + (__ffsll((long long)mask) - 1) : item;
+                const float4 j0 = items[2 * item2], j1 = items[2 * item2 + 1];
+                if (kPairs && mask != 0ull && (__builtin_amdgcn_readfirstlane((int)__float_as_uint(j0.w)) & 15) == RT_KIND_SPHERE_LEAF) {
+                    /* the next candidate is a leaf too (the leaves are the last items of the table): both box tests side by side */
+                    mask &= mask - 1ull;
+                    st_wave(st, ST_WAVE_BOX_TESTS); st_wave(st, ST_WAVE_BOX_TESTS);
+                    const bool needs_a = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
+                    const bool needs_b = !blocked && box_needed(j0, j1, o, inv, dist_to_light);
+                    const unsigned long long needers_a = __builtin_amdgcn_ballot_w64(needs_a);
+                    if (needers_a != 0ull) take_leaf(bits, needs_a, needers_a);
+                    /* rays that the first leaf has blocked meanwhile no longer need the second */
+                    const bool still_b = needs_b && !blocked;
+                    const unsigned long long needers_b = __builtin_amdgcn_ballot_w64(still_b);
+                    if (needers_b != 0ull) take_leaf(__float_as_uint(j0.w), still_b, needers_b);
+                    continue;
+                }
+#endif
                 st_wave(st, ST_WAVE_BOX_TESTS);
                 const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
                 const unsigned long long needers = __builtin_amdgcn_ballot_w64(lane_needs);
                 if (needers == 0ull) continue;
-                st_wave(st, ST_SHADOW_LEAVES_UNION);
-                if constexpr (kStats) stat_my_leaves += lane_needs ? 1 : 0;
-                if (kPairs && __popcll(needers) < RT_PAIR_DIRECT_LANES && n < 32) {      /* PAIRS, above */
-                    const int wanted = __popcll(needers);
-                    if (pairs.fill + wanted > 63) blocked = flush_shadow_pairs<kStats, kRoomy>(lds, pairs, o, d, dist_to_light, blocked, st);
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needers, 0u));
-                    /* every lane sends; the ones that do not need the leaf send to lane 63, which is never a slot */
-                    const int who = __builtin_amdgcn_ds_permute((lane_needs ? pairs.fill + rank : 63) << 2, lane);
-                    const bool fresh = lane >= pairs.fill && lane < pairs.fill + wanted;
-                    pairs.slot = fresh ? (who | (n << 6) | (int)((bits >> 16) << 11)) : pairs.slot;
-                    pairs.fill += wanted;
-                    continue;
-                }
-                blocked = leaf_members_block<kStats, kPairs>(g, n, o, d, dist_to_light, lane_needs, blocked, st);
+                take_leaf(bits, lane_needs, needers);
             } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves of a clustered run */
                 const int n_leaves = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
