@@ -570,23 +570,42 @@ __device__ __forceinline__ bool shadow_leaf_share(const float4 *lds, const float
                                                   unsigned long long leaf_mask, const int share, const int n_shares,
                                                   bool blocked, const V3 o, const V3 d, const V3 inv,
                                                   const float dist_to_light, Stats<kStats> &st) {
-    int turn = 0;
-    while (leaf_mask != 0ull) {
-        const int item = base + (__ffsll((long long)leaf_mask) - 1);
-        leaf_mask &= leaf_mask - 1ull;
-        const bool mine = turn == share;
-        turn = turn + 1 == n_shares ? 0 : turn + 1;
-        if (!mine) continue;
+    /* this share's leaves: every n_shares-th candidate, from candidate number `share` on */
+    unsigned long long mine = 0ull;
+    if (n_shares == 1) {
+        mine = leaf_mask;
+    } else {
+        int turn = 0;
+        for (unsigned long long rest = leaf_mask; rest != 0ull; rest &= rest - 1ull) {
+            if (turn == share) mine |= rest & (0ull - rest);
+            turn = turn + 1 == n_shares ? 0 : turn + 1;
+        }
+    }
+    /* two at a time: the box tests of two leaves side by side, like the owner's (RT_LEAVES_ABREAST) */
+    while (mine != 0ull) {
         if (!wave_any(!blocked)) return true;
+        const int item = base + (__ffsll((long long)mine) - 1);
+        mine &= mine - 1ull;
+        const bool two = mine != 0ull;
+        const int item2 = two ? base + (__ffsll((long long)mine) - 1) : item;
+        mine &= mine - 1ull;                            /* 0 stays 0 */
         const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
-        const uint32_t bits = __float_as_uint(i0.w);
-        const int n = (int)((bits >> 8) & 255u);
-        const float4 *g = lds + (bits >> 16);
+        const float4 j0 = items[2 * item2], j1 = items[2 * item2 + 1];
         st_wave(st, ST_WAVE_BOX_TESTS);
-        const bool lane_needs = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
-        if (!wave_any(lane_needs)) continue;
-        st_wave(st, ST_SHADOW_LEAVES_UNION);
-        blocked = leaf_members_block<kStats, true>(g, n, o, d, dist_to_light, lane_needs, blocked, st);
+        if (two) st_wave(st, ST_WAVE_BOX_TESTS);
+        const bool needs_a = !blocked && box_needed(i0, i1, o, inv, dist_to_light);
+        const bool needs_b = two && !blocked && box_needed(j0, j1, o, inv, dist_to_light);
+        if (wave_any(needs_a)) {
+            const uint32_t bits = __float_as_uint(i0.w);
+            st_wave(st, ST_SHADOW_LEAVES_UNION);
+            blocked = leaf_members_block<kStats, true>(lds + (bits >> 16), (int)((bits >> 8) & 255u), o, d, dist_to_light, needs_a, blocked, st);
+        }
+        const bool still_b = needs_b && !blocked;
+        if (wave_any(still_b)) {
+            const uint32_t bits = __float_as_uint(j0.w);
+            st_wave(st, ST_SHADOW_LEAVES_UNION);
+            blocked = leaf_members_block<kStats, true>(lds + (bits >> 16), (int)((bits >> 8) & 255u), o, d, dist_to_light, still_b, blocked, st);
+        }
     }
     return blocked;
 }
