@@ -111,6 +111,7 @@ typedef struct rt_launch_info {
     int32_t deferred_tiles;     /* tiles the last launch left to its second pass (-1: no second pass);
                                    reading it waits for the launch to finish                    */
     int32_t slices;             /* wavefronts that share a deferred tile's leaves in the second pass */
+    char    kernel[48];         /* name of the __global__ function the last launch ran (its first pass) */
 } rt_launch_info;
 
 /* Replaces: the Scene the reference keeps in the global my_scene
@@ -185,7 +186,8 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
 
 /* Tuning knobs (speed only, never results).  key:
  *   "tile_z"        wavefront tile height, 1,2,4,...,64 (width = 64 / height)
- *   "block_threads" 0 = auto, else 64, 128, 192 or 256
+ *   "block_threads" 0 = auto, else 64, 128, 192 or 256 (a value beyond the launch bounds of
+ *                   the kernel a launch picks -- 320..512 -- is refused by that launch)
  *   "stack"         bounce stack: 0 auto, 1 LDS, 2 HBM
  *   "pairs"         scenes with clustered sphere runs: 0 = every needed leaf is tested for
  *                   the whole wavefront (round 1's route); 1 (default) = the (ray, leaf)

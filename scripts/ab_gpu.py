@@ -17,7 +17,11 @@ for _ in range(reps):
                              env=env, capture_output=True, text=True, check=True).stdout
         for line in out.splitlines():
             f = line.split()
-            case, ms = f[0], float(f[3])
+            try:
+                k = f.index("ms")
+                case, ms = " ".join(f[:k - 2]) if f[0] == "twomirrors" else f[0], float(f[k - 1])
+            except (ValueError, IndexError):
+                continue
             best[case][n] = min(best[case].get(n, 1e9), ms)
 for case, d in best.items():
     print(f"{case:16s} " + "  ".join(f"{n}: {ms:8.3f} ms" for n, ms in d.items()), flush=True)

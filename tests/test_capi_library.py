@@ -38,7 +38,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(capi.RtTextureDesc) == 32
     assert C.sizeof(capi.RtCameraDesc) == 64
     assert C.sizeof(capi.RtTiming) == 48
-    assert C.sizeof(capi.RtLaunchInfo) == 32
+    assert C.sizeof(capi.RtLaunchInfo) == 32 + 48      # + kernel[48]
 
 
 def _create(desc):

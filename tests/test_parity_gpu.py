@@ -843,12 +843,51 @@ def test_counting_build_of_a_clustered_scene_both_passes(oracle):
             assert r.launch_info().deferred_tiles > 0
 
 
-def test_counting_build_refuses_tables_it_cannot_hold(oracle):
+def test_counting_build_keeps_tables_in_lds_whenever_they_fit(oracle):
+    """rt_render_stats has no global-memory variant: with the automatic placement (tables = 0) it
+    stages any scene that fits the 160 KiB of LDS -- two mirrors' 119 KB go to global memory in
+    the product kernel, to LDS here -- and refuses only what cannot work: tables = 2."""
     from tilecoderaytracer_amd import RtError, capi
+    want = oracle.OracleScene.two_mirrors().render(16, 16, 2)
     r = Renderer(HostScene.two_mirrors())                 # 119 KB of tables: global memory by default
+    assert_same(r.render(16, 16, 2), want, "two mirrors, tables in global memory")
+    assert r.launch_info().kernel == b"rt_render_kernel_large"
+    img, _ = r.render_stats(16, 16, 2)
+    assert_same(img, want, "counting build, two mirrors (automatic placement)")
+    r.set_option("tables", 2)
     with pytest.raises(RtError) as e:
         r.render_stats(16, 16, 2)
-    assert e.value.code == capi.RT_ERR_CAPACITY
+    assert e.value.code == capi.RT_ERR_CAPACITY and "tables" in e.value.message
     r.set_option("tables", 1)                              # they do fit LDS
     img, _ = r.render_stats(16, 16, 2)
-    assert_same(img, oracle.OracleScene.two_mirrors().render(16, 16, 2), "counting build, two mirrors in LDS")
+    assert_same(img, want, "counting build, two mirrors in LDS")
+
+
+def test_launch_refuses_a_workgroup_beyond_the_kernels_launch_bounds(oracle):
+    """block_threads up to 512 is accepted as an option (the counting kernels take it), but a launch
+    whose kernel was compiled for 256 threads refuses it instead of faulting (round-2 experiment 18)."""
+    from tilecoderaytracer_amd import RtError, capi
+    for name in ("builtin", "grid16"):
+        r = Renderer(HostScene.named(name))
+        r.set_option("block_threads", 512)
+        with pytest.raises(RtError) as e:
+            r.render(64, 64, 2)
+        assert e.value.code == capi.RT_ERR_INVALID and "launch bounds" in e.value.message
+        r.set_option("block_threads", 256)
+        assert_same(r.render(64, 64, 2), oracle.OracleScene.named(name).render(64, 64, 2), f"{name} after the refusal")
+
+
+def test_fast_tables_against_item_tables(oracle):
+    """Scenes without clustered runs: the kind-sorted item list with direct records (option fast = 1, the
+    default) and the two item tables (fast = 0) render the same image, and so do the tight plane boxes."""
+    want = oracle.OracleScene.builtin().render(200, 152, 6)
+    r = Renderer(HostScene.builtin())
+    assert_same(r.render(200, 152, 6), want, "fast tables")
+    assert r.launch_info().kernel == b"rt_render_kernel"
+    r.set_option("fast", 0)
+    assert_same(r.render(200, 152, 6), want, "item tables")
+    assert r.launch_info().kernel == b"rt_render_kernel_items"
+    r.set_option("tight_planes", 0)
+    assert_same(r.render(200, 152, 6), want, "item tables, sphere padding for planes")
+    r.set_option("fast", 1)
+    assert_same(r.render(200, 152, 6), want, "fast tables, sphere padding for planes")

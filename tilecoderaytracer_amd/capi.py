@@ -62,7 +62,7 @@ class RtLaunchInfo(C.Structure):
     _fields_ = [
         ("block_threads", C.c_int32), ("lds_bytes", C.c_int32), ("scene_lds_bytes", C.c_int32),
         ("grid_blocks", C.c_int32), ("tile_x", C.c_int32), ("tile_z", C.c_int32),
-        ("deferred_tiles", C.c_int32), ("slices", C.c_int32),
+        ("deferred_tiles", C.c_int32), ("slices", C.c_int32), ("kernel", C.c_char * 48),
     ]
 
 

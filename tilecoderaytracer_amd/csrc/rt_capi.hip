@@ -25,6 +25,19 @@ extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__re
                                             float4 *__restrict__ bounce_stack,
                                             unsigned int *__restrict__ defer_list);
 
+extern "C" __global__ void rt_render_kernel_items(const RtParams p, const float4 *__restrict__ image,
+                                                  float *__restrict__ out,
+                                                  unsigned int *__restrict__ tile_counter,
+                                                  float4 *__restrict__ bounce_stack,
+                                                  unsigned int *__restrict__ defer_list);
+
+extern "C" __global__ void rt_render_kernel_fast_stats(const RtParams p, const float4 *__restrict__ image,
+                                                       float *__restrict__ out,
+                                                       unsigned int *__restrict__ tile_counter,
+                                                       float4 *__restrict__ bounce_stack,
+                                                       unsigned long long *__restrict__ stats_out,
+                                                       unsigned int *__restrict__ defer_list);
+
 extern "C" __global__ void rt_render_kernel_large(const RtParams p, const float4 *__restrict__ image,
                                                   float *__restrict__ out,
                                                   unsigned int *__restrict__ tile_counter,
@@ -127,6 +140,8 @@ struct rt_scene {
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int leaf_items_opt = 1;       /* clustered runs appear in the item tables leaf by leaf (0: group by group) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
+    int fast_opt = 1;             /* scenes without clustered runs: the kind-sorted item list with direct records (FAST tables); 0: the two item tables */
+    int tight_planes = 1;         /* plane items: boxes padded for a plane's rounding only (RT_ITEM_TIGHT); 0: the sphere padding */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
     int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
     int cull_opt = 1;             /* 0: plain in-order scans -- no bundle cull, no nearest-first exit, no clustering, no AA route */
@@ -423,11 +438,28 @@ int pack_scene(rt_scene *s) {
     image.resize(image.size() + (cidx.size() + 3) / 4, Quad{{0, 0, 0, 0}});
     if (!cidx.empty()) std::memcpy(image[(size_t)cidx_off].v, cidx.data(), cidx.size() * 4);
 
+    /* FAST tables (rt_tables.h): scenes without clustered runs get one kind-sorted item list with direct test
+     * records instead of the two item tables (and the sections only those refer to) */
+    /* (only while the tables go to LDS: the large-scene kernel reads the item tables) */
+    const size_t fast_quads = geom.size() + (size_t)n * (RT_FAST_BOX_QUADS + RT_FAST_REC_QUADS) + lights.size() + mats.size() +
+                              texs.size() + 2 * (((size_t)n + 3) / 4);
+    const bool fast = s->cull_opt && s->fast_opt && n_clusters == 0 && n > 0 && s->tables_opt != 2 &&
+                      fast_quads * 16 <= (s->tables_opt == 1 ? (size_t)RT_MAX_LDS_BYTES : (size_t)RT_LDS_TABLE_BYTES);
+    std::vector<uint32_t> fast_ctl;
+    std::vector<Quad> fast_boxes, fast_recs;
+    int fast_n_shadow = 0;
     /* Item tables (rt_tables.h): one item per object that is not part of a clustered run, in
      * Scene order, then one per leaf (or group) of each clustered run.  `near_items` covers every object,
      * `shadow_items` the non-light objects of the shadow scan range. */
     {
         const float INF = INFINITY;
+        /* Padding.  A sphere's box also has to hold what the reference's coarse float sphere test reports
+         * (box_needed() in rt_kernel.hip): 1 % of its extent here plus the kernel's distance-proportional
+         * RT_SPHERE_SLACK.  A plane's hit point p = t d + o is exact up to the rounding of the sum, a few ulp
+         * of the coordinates involved: 1e-4 of the box's magnitude (500 ulp) covers the part that scales with
+         * where the rectangle is, the kernel's RT_PLANE_SLACK the part that scales with the distance travelled;
+         * such items carry RT_ITEM_TIGHT.  (With the sphere padding a 14-unit wall was 0.28 thick and, e.g., a
+         * light 0.01 in front of it made it a candidate of every shadow scan towards that light.) */
         auto box_item = [&](std::vector<Quad> &out, const double lo[3], const double hi[3], uint32_t bits,
                             uint32_t word1, bool unbounded) {
             double ext = 0.0, mag = 0.0;
@@ -435,7 +467,7 @@ int pack_scene(rt_scene *s) {
                 ext = std::max(ext, hi[k] - lo[k]);
                 mag = std::max(mag, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
             }
-            const double pad = 1e-4 + 1e-4 * mag + 1e-2 * ext;
+            const double pad = 1e-4 + 1e-4 * mag + ((bits & RT_ITEM_TIGHT) ? 0.0 : 1e-2 * ext);
             Quad q0, q1;
             for (int k = 0; k < 3; ++k) {
                 const bool ok = !unbounded && std::isfinite(lo[k]) && std::isfinite(hi[k]) && std::isfinite(pad);
@@ -492,11 +524,12 @@ int pack_scene(rt_scene *s) {
                     }
                 }
                 if (unbounded) { for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = 0.0; } }
+                const uint32_t tight = s->tight_planes ? (uint32_t)RT_ITEM_TIGHT : 0u;
                 if (aa_rec_of[(size_t)i] >= 0)
-                    box_item(out, lo, hi, (uint32_t)(RT_KIND_FINITE_AA + aa_cls_of[(size_t)i]) |
+                    box_item(out, lo, hi, (uint32_t)(RT_KIND_FINITE_AA + aa_cls_of[(size_t)i]) | tight |
                                               ((uint32_t)(aa_off + aa_rec_of[(size_t)i]) << 16), word1, unbounded);
                 else
-                    box_item(out, lo, hi, (uint32_t)RT_KIND_FINITE_PLANE | (full << 16), word1, unbounded);
+                    box_item(out, lo, hi, (uint32_t)RT_KIND_FINITE_PLANE | tight | (full << 16), word1, unbounded);
             }
         };
         auto group_item = [&](std::vector<Quad> &out, const GroupItem &g) {
@@ -532,12 +565,60 @@ int pack_scene(rt_scene *s) {
             for (const GroupItem &g : group_items)
                 if (g.in_shadow) group_item(shadow_items, g);
         }
+        if (fast) {
+            auto kind_rank = [&](int i) {
+                if (aa_rec_of[(size_t)i] >= 0) return aa_cls_of[(size_t)i];                 /* 0..2: AA rectangles by normal axis */
+                return objs[i].kind == RT_KIND_SPHERE ? 3 : objs[i].kind == RT_KIND_FINITE_PLANE ? 4 : 5;
+            };
+            std::vector<int> order;
+            for (int part = 0; part < 2; ++part)
+                for (int rank = 0; rank < 6; ++rank)
+                    for (int i = 0; i < n; ++i) {
+                        const bool in_shadow = i >= sb && i < se && !objs[i].is_light;
+                        if ((part == 0) == in_shadow && kind_rank(i) == rank) order.push_back(i);
+                    }
+            for (int i : order) {
+                const rt_object_desc &o = objs[i];
+                if (i >= sb && i < se && !o.is_light) ++fast_n_shadow;
+                std::vector<Quad> item;
+                object_item(item, i);
+                const uint32_t kind = aa_rec_of[(size_t)i] >= 0 ? (uint32_t)(RT_KIND_FINITE_AA + aa_cls_of[(size_t)i]) : (uint32_t)o.kind;
+                const uint32_t ctl = kind | ((uint32_t)i << 8);
+                uint32_t bits0; std::memcpy(&bits0, &item[0].v[3], 4);
+                item[0].v[3] = bits_to_float(kind | (bits0 & RT_ITEM_TIGHT));
+                item[1].v[3] = bits_to_float(ctl);
+                fast_boxes.push_back(item[0]);
+                fast_boxes.push_back(item[1]);
+                fast_ctl.push_back(ctl);
+                if (aa_rec_of[(size_t)i] >= 0) {
+                    fast_recs.push_back(aa_recs[(size_t)aa_rec_of[(size_t)i]]);
+                    fast_recs.push_back(aa_recs[(size_t)aa_rec_of[(size_t)i] + 1]);
+                } else if (o.kind == RT_KIND_SPHERE) {
+                    fast_recs.push_back({{o.origin[0], o.origin[1], o.origin[2], o.radius_squared}});
+                    fast_recs.push_back({{0, 0, 0, 0}});
+                } else {
+                    fast_recs.push_back({{o.normal[0], o.normal[1], o.normal[2], o.distance_to_origin}});
+                    fast_recs.push_back({{bits_to_float((uint32_t)geom_off[(size_t)i]), 0, 0, 0}});
+                }
+            }
+        }
+    }
+    if (fast) {
+        image.assign(geom.begin(), geom.end());                /* no leaves, no aa section, no cidx */
+        b.n_fast_items = (int)fast_ctl.size();
+        b.n_fast_shadow = fast_n_shadow;
+        b.fast_box_off = (int)image.size();
+        image.insert(image.end(), fast_boxes.begin(), fast_boxes.end());
+        b.fast_rec_off = (int)image.size();
+        image.insert(image.end(), fast_recs.begin(), fast_recs.end());
+        near_items.clear();
+        shadow_items.clear();
     }
     b.near_items_off = (int)image.size();
-    b.n_near_items = (int)(near_items.size() / 2);
+    b.n_near_items = fast ? b.n_fast_items : (int)(near_items.size() / 2);
     image.insert(image.end(), near_items.begin(), near_items.end());
     b.shadow_items_off = (int)image.size();
-    b.n_shadow_items = (int)(shadow_items.size() / 2);
+    b.n_shadow_items = fast ? b.n_fast_shadow : (int)(shadow_items.size() / 2);
     image.insert(image.end(), shadow_items.begin(), shadow_items.end());
     b.lights_off = (int)image.size();
     image.insert(image.end(), lights.begin(), lights.end());
@@ -548,6 +629,11 @@ int pack_scene(rt_scene *s) {
     b.objinfo_off = (int)image.size();
     image.resize(image.size() + ((size_t)n + 3) / 4, Quad{{0, 0, 0, 0}});
     if (n > 0) std::memcpy(image[(size_t)b.objinfo_off].v, objinfo.data(), (size_t)n * 4);
+    if (fast) {
+        b.fast_ctl_off = (int)image.size() * 4;
+        image.resize(image.size() + (fast_ctl.size() + 3) / 4, Quad{{0, 0, 0, 0}});
+        std::memcpy(image[(size_t)b.fast_ctl_off / 4].v, fast_ctl.data(), fast_ctl.size() * 4);
+    }
     if (image.empty()) image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
     b.image_quads = (int)image.size();
     b.n_clusters = n_clusters;
@@ -676,12 +762,14 @@ int horizon_start(const rt_scene *s, const rt_camera_desc *cam) {
  * tables while RT_STACK_LDS_SHARE workgroups per CU still fit in the 160 KiB
  * (nearly every reflection chain uses the first levels, few the deep ones); the
  * rest lives in HBM.  Option "stack": 1 = all of it in LDS, 2 = all in HBM. */
-int choose_block(const rt_scene *s, int max_depth, int *block, int *lds_bytes, int *stack_lds_levels, bool *global_tables) {
+int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, int *lds_bytes, int *stack_lds_levels, bool *global_tables) {
     /* Tables in LDS (staged once per workgroup), or -- large scenes -- left in global memory and read
      * through the L2 (rt_render_kernel_large): automatic beyond RT_LDS_TABLE_BYTES, where LDS would hold
      * fewer than two workgroups per CU; beyond 160 KiB it is the only way.  Option "tables". */
     size_t scene_bytes = (size_t)s->base.image_quads * 16;
-    *global_tables = s->tables_opt == 2 || (s->tables_opt == 0 && scene_bytes > RT_LDS_TABLE_BYTES);
+    /* the counting build has no global-memory variant: automatic means LDS for it whenever the tables fit at all */
+    *global_tables = s->tables_opt == 2 ||
+                     (s->tables_opt == 0 && scene_bytes > (counting ? (size_t)RT_MAX_LDS_BYTES : (size_t)RT_LDS_TABLE_BYTES));
     if (!*global_tables && scene_bytes > RT_MAX_LDS_BYTES)
         return fail(RT_ERR_CAPACITY, "option tables=1: the scene tables do not fit in LDS (160 KiB)");
     if (*global_tables) scene_bytes = 0;
@@ -718,10 +806,12 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
 
     int block = 0, lds_bytes = 0, stack_lds_levels = 0;
     bool global_tables = false;
-    int rc = choose_block(s, max_depth, &block, &lds_bytes, &stack_lds_levels, &global_tables);
+    int rc = choose_block(s, max_depth, d_stats != nullptr, &block, &lds_bytes, &stack_lds_levels, &global_tables);
     if (rc) return rc;
     if (global_tables && d_stats)
-        return fail(RT_ERR_CAPACITY, "the counting build keeps the tables in LDS: this scene's do not fit (or option tables=2 is set)");
+        return fail(RT_ERR_CAPACITY, s->tables_opt == 2
+                        ? "the counting build keeps the tables in LDS: set option tables to 0 or 1 for it"
+                        : "the counting build keeps the tables in LDS: this scene's exceed 160 KiB");
 
     RtParams p = s->base;
     for (int c = 0; c < 3; ++c) {
@@ -831,12 +921,26 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         }
     }
     const bool clusters_wide = (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
-    const void *first = d_stats ? (const void *)rt_render_kernel_stats
-                        : global_tables ? (const void *)rt_render_kernel_large
-                        : p.defer_leaves != 0 ? (const void *)rt_render_kernel_deferring
-                        : (s->n_clusters > 0 && s->pairs_opt)
-                              ? (clusters_wide ? (const void *)rt_render_kernel_clusters_wide : (const void *)rt_render_kernel_clusters)
-                              : (const void *)rt_render_kernel;
+    const bool fast_tables = s->base.n_fast_items > 0;
+    struct Kernel { const void *fn; const char *name; };
+#define RT_KERNEL(k) Kernel{(const void *)k, #k}
+    const Kernel first_kernel = d_stats ? (fast_tables ? RT_KERNEL(rt_render_kernel_fast_stats) : RT_KERNEL(rt_render_kernel_stats))
+                                : global_tables ? RT_KERNEL(rt_render_kernel_large)
+                                : p.defer_leaves != 0 ? RT_KERNEL(rt_render_kernel_deferring)
+                                : (s->n_clusters > 0 && s->pairs_opt)
+                                      ? (clusters_wide ? RT_KERNEL(rt_render_kernel_clusters_wide) : RT_KERNEL(rt_render_kernel_clusters))
+                                : fast_tables ? RT_KERNEL(rt_render_kernel)
+                                : RT_KERNEL(rt_render_kernel_items);
+    const void *first = first_kernel.fn;
+    std::snprintf(s->launch.kernel, sizeof(s->launch.kernel), "%s", first_kernel.name);
+    {
+        /* a workgroup larger than the kernel was compiled for (__launch_bounds__) must never be launched */
+        hipFuncAttributes attr;
+        HIP_TRY(hipFuncGetAttributes(&attr, first));
+        if (block > attr.maxThreadsPerBlock)
+            return fail(RT_ERR_INVALID, "block_threads " + std::to_string(block) + " exceeds the launch bounds of " +
+                                            first_kernel.name + " (" + std::to_string(attr.maxThreadsPerBlock) + ")");
+    }
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, first, block, (size_t)lds_bytes));
     if (per_cu < 1) per_cu = 1;
@@ -895,30 +999,16 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     s->ev[slot].two_passes = p.defer_leaves != 0;
     s->launch.deferred_tiles = p.defer_leaves != 0 ? 0 : -1;
     s->launch.slices = block2 / 64;
-    if (d_stats)
-        hipLaunchKernelGGL(rt_render_kernel_stats, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes,
-                           stream, p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
-    else if (global_tables)
-        hipLaunchKernelGGL(rt_render_kernel_large, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
-                           p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
-    else if (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt && clusters_wide)
-        hipLaunchKernelGGL(rt_render_kernel_clusters_wide, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
-                           p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), reinterpret_cast<unsigned int *>(s->d_help));
-    else if (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt)
-        hipLaunchKernelGGL(rt_render_kernel_clusters, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
-                           p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), reinterpret_cast<unsigned int *>(s->d_help));
-    else if (p.defer_leaves != 0)
-        hipLaunchKernelGGL(rt_render_kernel_deferring, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
-                           p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
-    else
-        hipLaunchKernelGGL(rt_render_kernel, dim3((unsigned)blocks), dim3((unsigned)block), (size_t)lds_bytes, stream,
-                           p, reinterpret_cast<const float4 *>(s->d_image),
-                           d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+    const float4 *image_arg = reinterpret_cast<const float4 *>(s->d_image);
+    float4 *stack_arg = reinterpret_cast<float4 *>(s->d_stack);
+    /* the clustered-scene kernels get the workgroups' HELP areas where the others get the defer list */
+    unsigned int *list_arg = (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt && !d_stats && !global_tables)
+                                 ? reinterpret_cast<unsigned int *>(s->d_help) : s->d_defer;
+    {
+        void *args6[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &list_arg};
+        void *args7[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &d_stats, &list_arg};
+        HIP_TRY(hipLaunchKernel(first, dim3((unsigned)blocks), dim3((unsigned)block), d_stats ? args7 : args6, (size_t)lds_bytes, stream));
+    }
     if (p.defer_leaves != 0) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev[slot].mid, stream));
@@ -932,14 +1022,11 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         if (per_cu2 < 1) per_cu2 = 1;
         /* never more workgroups than the first pass: the bounce stack has one slice per workgroup */
         const long long blocks2 = std::min(blocks, (long long)per_cu2 * (long long)s->n_cus);
-        if (d_stats)
-            hipLaunchKernelGGL(rt_render_kernel_second_stats, dim3((unsigned)blocks2), dim3((unsigned)block2), lds_bytes2,
-                               stream, p, reinterpret_cast<const float4 *>(s->d_image),
-                               d_out, counter, reinterpret_cast<float4 *>(s->d_stack), d_stats, s->d_defer);
-        else
-            hipLaunchKernelGGL(rt_render_kernel_second, dim3((unsigned)blocks2), dim3((unsigned)block2), lds_bytes2, stream,
-                               p, reinterpret_cast<const float4 *>(s->d_image),
-                               d_out, counter, reinterpret_cast<float4 *>(s->d_stack), s->d_defer);
+        {
+            void *args6[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &s->d_defer};
+            void *args7[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &d_stats, &s->d_defer};
+            HIP_TRY(hipLaunchKernel(second, dim3((unsigned)blocks2), dim3((unsigned)block2), d_stats ? args7 : args6, lds_bytes2, stream));
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
@@ -1134,8 +1221,8 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
     if (!std::strcmp(key, "block_threads")) {
-        if (value != 0 && (value < 64 || value > 256 || (value % 64) != 0))        /* the kernel's launch bound is 256 */
-            return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or 64, 128, 192 or 256");
+        if (value != 0 && (value < 64 || value > 512 || (value % 64) != 0))        /* launch() refuses what exceeds the chosen kernel's launch bounds */
+            return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or a multiple of 64 up to 512 (the render kernels take up to 256)");
         s->block_threads_opt = value;
         return RT_OK;
     }
@@ -1158,11 +1245,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         s->pairs_opt = value != 0;
         return RT_OK;
     }
-    if (!std::strcmp(key, "tables")) {
-        if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tables must be 0 (auto), 1 (LDS) or 2 (global memory)");
-        s->tables_opt = value;
-        return RT_OK;
-    }
+
     if (!std::strcmp(key, "second_block")) {
         if (value != 0 && (value < 64 || value > 512 || (value % 64) != 0))
             return fail(RT_ERR_INVALID, "second_block must be 0 (auto) or a multiple of 64 up to 512");
@@ -1198,6 +1281,12 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     };
     if (!std::strcmp(key, "leaf_items")) return repack_with(s->leaf_items_opt, value != 0);
     if (!std::strcmp(key, "aa_planes")) return repack_with(s->aa_planes, value != 0);
+    if (!std::strcmp(key, "tight_planes")) return repack_with(s->tight_planes, value != 0);
+    if (!std::strcmp(key, "fast")) return repack_with(s->fast_opt, value != 0);
+    if (!std::strcmp(key, "tables")) {             /* decides the table format too (FAST tables live in LDS) */
+        if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tables must be 0 (auto), 1 (LDS) or 2 (global memory)");
+        return repack_with(s->tables_opt, value);
+    }
     if (!std::strcmp(key, "cull")) return repack_with(s->cull_opt, value != 0);
     if (!std::strcmp(key, "cluster_leaf") || !std::strcmp(key, "cluster_group")) {
         const bool leaf = !std::strcmp(key, "cluster_leaf");

@@ -314,6 +314,14 @@ __device__ __forceinline__ void aa_rectangle_distance(const float4 r0, const flo
 #ifndef RT_SPHERE_SLACK
 #define RT_SPHERE_SLACK 1.5e-3f
 #endif
+/* the same for items that are finite planes (RT_ITEM_TIGHT, rt_tables.h).  The reference's hit point is
+ * p = t d + o in floats (src/SceneFinitePlane.cpp:106-116): off the exact ray by at most 2^-23 (|t d_k| + |p_k|)
+ * per axis -- the second term is covered by the host's padding of the box (1e-4 of its magnitude), the first is
+ * 1.2e-7 of the distance travelled; the ray's direction is a unit vector to 2e-7.  1e-5 of the L1 distance
+ * leaves a factor of 30 to both. */
+#ifndef RT_PLANE_SLACK
+#define RT_PLANE_SLACK 1.0e-5f
+#endif
 
 __device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
     /* a NaN or infinity in any component makes the sum non-finite */
@@ -816,7 +824,8 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             float ay = b0.y - omaxy, by = b1.y - ominy;
             float az = b0.z - omaxz, bz = b1.z - ominz;
             const float far = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) + fmaxf(fabsf(az), fabsf(bz));
-            const float ex = RT_SPHERE_SLACK * far + 1.0e-4f;
+            /* a plane's hit point is off its ray by rounding only (RT_PLANE_SLACK); a sphere's box has to hold the coarse float test */
+            const float ex = ((__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? RT_PLANE_SLACK : RT_SPHERE_SLACK) * far + 1.0e-4f;
             ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
             /* feasible t: [t_lo, t_hi], starting from [0, 65535 (the reference's infinity) + slack] */
             /* t dmin <= b and t dmax >= a per axis, as lower / upper bounds of t through
@@ -1094,11 +1103,15 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
     const bool cull = p.cull != 0 && p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS;
     const V3 c = origins_centre;             /* both from shading_point_bundle(), once per bounce level */
     V3 e = origins_half, sinv = mk(0, 0, 0); /* e: half-extent, plus slack below */
+    float grow_more = 0.0f;
     if (cull) {
         const V3 seg = sub3(light, c);
         sinv = approx_inverse(seg);
-        const float grow = RT_SPHERE_SLACK * ((fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z)) + 1.0e-4f;
-        /* the same in every lane: keep them in scalar registers */
+        const float reach = (fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z);
+        /* the same in every lane: keep them in scalar registers.  `e` carries the slack of a plane item
+         * (RT_ITEM_TIGHT); sphere-like items add `grow_more` */
+        grow_more = uniform_f((RT_SPHERE_SLACK - RT_PLANE_SLACK) * reach);
+        const float grow = RT_PLANE_SLACK * reach + 1.0e-4f;
         e = mk(uniform_f(e.x + grow), uniform_f(e.y + grow), uniform_f(e.z + grow));
         sinv = mk(uniform_f(sinv.x), uniform_f(sinv.y), uniform_f(sinv.z));
     }
@@ -1112,7 +1125,8 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
         if (cull) {
             const int mine = min(base + lane, p.n_shadow_items - 1);
             const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
-            const float gx = e.x, gy = e.y, gz = e.z;
+            const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
+            const float gx = e.x + more, gy = e.y + more, gz = e.z + more;
             const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
             const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
             const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
@@ -1290,6 +1304,196 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
     return blocked;
 }
 
+/* ---- FAST tables (rt_tables.h): the scans of scenes without clustered sphere runs ------------------------
+ * One kind-sorted item list serves both scans; a candidate's exact test reads its two record quads from LDS at
+ * an address computed from the (scalar) item number, and its kind and Scene index arrive in a scalar register
+ * (s_load from the image in global memory): one LDS round trip per candidate where the item tables need two
+ * dependent ones, and no vector instruction spent on dispatch.  The culls are the ones of nearest_hit_items()
+ * and in_shade(); the tests are the same routines on the same operands. */
+
+/* one candidate's exact distance test, dispatched on the (scalar) kind */
+template <bool kStats>
+__device__ __forceinline__ void fast_item_distance(const RtParams &p, const float4 *lds, const uint32_t ctl,
+                                                   const float4 r0, const float4 r1, const V3 o, const V3 d,
+                                                   const float bound, const bool finite_rays, const bool counts,
+                                                   bool *hit, float *t, Stats<kStats> &st) {
+    const int kind = (int)(ctl & 15u);
+    if (kind >= RT_KIND_FINITE_AA && finite_rays) {
+        st_wave(st, ST_WAVE_PLANE_TESTS);
+        /* one copy of the test per axis of the normal: the rotation of the ray costs nothing then */
+        if (kind == RT_KIND_FINITE_AA)          aa_rectangle_distance(r0, r1, mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), bound, hit, t);
+        else if (kind == RT_KIND_FINITE_AA + 1) aa_rectangle_distance(r0, r1, mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), bound, hit, t);
+        else                                    aa_rectangle_distance(r0, r1, mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), bound, hit, t);
+    } else if (kind == RT_KIND_SPHERE) {
+        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, counts);
+        sphere_distance(r0, o, d, hit, t);
+    } else if (kind == RT_KIND_INFINITE_PLANE) {
+        st_wave(st, ST_WAVE_PLANE_TESTS);
+        infinite_plane_distance(r0, o, d, bound, hit, t);
+    } else {
+        /* a finite plane that is not axis-aligned -- or is, but some ray has a non-finite component: the general
+         * routine on the full record (an AA item finds it through its Scene index) */
+        st_wave(st, ST_WAVE_PLANE_TESTS);
+        const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
+        const uint32_t full = kind == RT_KIND_FINITE_PLANE ? __float_as_uint(r1.x) : (lds_u32[p.objinfo_off * 4 + (ctl >> 8)] & 0xFFFFu);
+        finite_plane_distance(lds + full, o, d, bound, hit, t);
+    }
+}
+
+/* getCollision (src/RayTracer.cpp:50-89) over the FAST item list; the cull and the nearest-first order are
+ * nearest_hit_items()'s (see there for why they are exact) */
+template <bool kStats>
+__device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4 *lds, const uint32_t *__restrict__ ctl_words,
+                                                 const bool active, const V3 o, const V3 d, const bool have_origin_box,
+                                                 const V3 origins_lo, const V3 origins_hi,
+                                                 float *best_out, int *best_idx_out, Stats<kStats> &st) {
+    float best = 65535.0f;
+    int best_idx = -1;
+    st_lane(st, ST_NEAREST_RAYS, active);
+    st_wave(st, ST_WAVE_NEAREST);
+    const int lane = (int)(threadIdx.x & 63u);
+    const float inf = __builtin_huge_valf();
+    const int n_items = p.n_fast_items;
+
+    float dminx = -inf, dmaxx = inf, dminy = -inf, dmaxy = inf, dminz = -inf, dmaxz = inf;
+    bool cull = n_items >= RT_NEAR_CULL_MIN_ITEMS;
+    if (cull) {
+        V3 dlo, dhi;
+        wave_bounds3(d, active, &dlo, &dhi);
+        dminx = dlo.x; dminy = dlo.y; dminz = dlo.z; dmaxx = dhi.x; dmaxy = dhi.y; dmaxz = dhi.z;
+        cull = !((dminx < 0.0f && dmaxx > 0.0f) && (dminy < 0.0f && dmaxy > 0.0f) && (dminz < 0.0f && dmaxz > 0.0f));
+        if (!cull) st_wave(st, ST_NEAREST_UNCULLED);
+    }
+    float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
+    float lax = 0, hax = 0, lbx = 0, hbx = 0, lay = 0, hay = 0, lby = 0, hby = 0, laz = 0, haz = 0, lbz = 0, hbz = 0;
+    if (cull) {
+        if (have_origin_box) {
+            ominx = origins_lo.x; ominy = origins_lo.y; ominz = origins_lo.z;
+            omaxx = origins_hi.x; omaxy = origins_hi.y; omaxz = origins_hi.z;
+        } else {
+            V3 olo, ohi;
+            wave_bounds3(o, active, &olo, &ohi);
+            ominx = olo.x; ominy = olo.y; ominz = olo.z; omaxx = ohi.x; omaxy = ohi.y; omaxz = ohi.z;
+        }
+        bound_multipliers(dminx, dmaxx, &lax, &hax, &lbx, &hbx);
+        bound_multipliers(dminy, dmaxy, &lay, &hay, &lby, &hby);
+        bound_multipliers(dminz, dmaxz, &laz, &haz, &lbz, &hbz);
+    }
+    const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
+    const float4 *boxes = lds + p.fast_box_off;
+    const float4 *recs = lds + p.fast_rec_off;
+
+    for (int base = 0; base < n_items; base += 64) {
+        unsigned long long mask;
+        uint32_t key = 0xFFFFFFFFu;
+        if (cull) {
+            const int mine = min(base + lane, n_items - 1);
+            const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
+            float ax = b0.x - omaxx, bx = b1.x - ominx;
+            float ay = b0.y - omaxy, by = b1.y - ominy;
+            float az = b0.z - omaxz, bz = b1.z - ominz;
+            const float far = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) + fmaxf(fabsf(az), fabsf(bz));
+            const float ex = ((__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? RT_PLANE_SLACK : RT_SPHERE_SLACK) * far + 1.0e-4f;
+            ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
+            const float t_lo = fmaxf(fmaxf(fmaxf(0.0f, fmaxf(bx * lax, ax * lbx)), fmaxf(by * lay, ay * lby)), fmaxf(bz * laz, az * lbz));
+            const float t_hi = fminf(fminf(fminf(65600.0f, fminf(bx * hax, ax * hbx)), fminf(by * hay, ay * hby)), fminf(bz * haz, az * hbz));
+            const bool empty = (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi)) || (t_hi < -1.0e-6f);
+            const bool candidate = base + lane < n_items && !empty;
+            mask = __builtin_amdgcn_ballot_w64(candidate);
+            if (candidate) key = (__float_as_uint(t_lo) & ~63u) | (uint32_t)lane;
+        } else {
+            const int left = n_items - base;
+            mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        }
+        const bool ordered = cull && __popcll(mask) >= RT_ORDER_MIN_CANDIDATES;
+        while (mask != 0ull) {
+            int src;
+            if (ordered) {
+                const uint32_t nearest_key = wave_min_u32(key);
+                if (nearest_key == 0xFFFFFFFFu) break;
+                src = (int)(nearest_key & 63u);
+                const float entry = __uint_as_float(nearest_key & ~63u);
+                if (entry > 0.0f && !wave_any(active && !(entry - 1.0e-4f * entry - 1.0e-6f > best))) break;
+                if (lane == src) key = 0xFFFFFFFFu;
+                mask &= ~(1ull << src);
+            } else {
+                src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1ull;
+            }
+            const int item = base + src;
+            const uint32_t ctl = ctl_words[item];
+            const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
+            bool hit; float t;
+            fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, best, finite_rays, active, &hit, &t, st);
+            const int idx = (int)(ctl >> 8);
+            if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
+        }
+    }
+    *best_out = best;
+    *best_idx_out = active ? best_idx : -1;
+}
+
+/* inShade (src/RayTracer.cpp:709-771) over the first n_fast_shadow items of the FAST list; in_shade()'s cull */
+template <bool kStats>
+__device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *lds, const uint32_t *__restrict__ ctl_words,
+                                              const bool active, const V3 o, const V3 d, const float dist_to_light,
+                                              const V3 light, const V3 origins_centre, const V3 origins_half, Stats<kStats> &st) {
+    const int n_items = p.n_fast_shadow;
+    bool blocked = !active;
+    if (n_items == 0) return false;
+    st_lane(st, ST_SHADOW_RAYS, active);
+    st_wave(st, ST_WAVE_SHADOW);
+    const bool cull = n_items >= RT_SHADOW_CULL_MIN_ITEMS;
+    const V3 c = origins_centre;
+    V3 e = origins_half, sinv = mk(0, 0, 0);
+    float grow_more = 0.0f;
+    if (cull) {
+        const V3 seg = sub3(light, c);
+        sinv = approx_inverse(seg);
+        const float reach = (fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z);
+        grow_more = uniform_f((RT_SPHERE_SLACK - RT_PLANE_SLACK) * reach);
+        const float grow = RT_PLANE_SLACK * reach + 1.0e-4f;
+        e = mk(uniform_f(e.x + grow), uniform_f(e.y + grow), uniform_f(e.z + grow));
+        sinv = mk(uniform_f(sinv.x), uniform_f(sinv.y), uniform_f(sinv.z));
+    }
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
+    const float4 *boxes = lds + p.fast_box_off;
+    const float4 *recs = lds + p.fast_rec_off;
+    for (int base = 0; base < n_items; base += 64) {
+        unsigned long long mask;
+        if (cull) {
+            const int mine = min(base + lane, n_items - 1);
+            const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
+            const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
+            const float gx = e.x + more, gy = e.y + more, gz = e.z + more;
+            const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
+            const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
+            const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
+            const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
+                               (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
+            mask = __builtin_amdgcn_ballot_w64(base + lane < n_items && !apart);
+        } else {
+            const int left = n_items - base;
+            mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        }
+        if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
+        while (mask != 0ull) {
+            const int item = base + (__ffsll((long long)mask) - 1);
+            mask &= mask - 1ull;
+            if (!wave_any(!blocked)) return true;
+            const uint32_t ctl = ctl_words[item];
+            const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
+            bool hit; float t;
+            fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, dist_to_light, finite_rays, !blocked, &hit, &t, st);
+            blocked = blocked || (hit && t < dist_to_light);
+        }
+    }
+    return blocked;
+}
+
 /* Texture_CheckerBoard::getTexturePixel, src/Texture_CheckerBoard.h:31-65.
  * Returns 1 for the light colour, 2 for the dark colour. */
 /* fmodf(x, y) for 0 <= x < 2^20 y, y a normal number well inside the exponent
@@ -1351,7 +1555,7 @@ __device__ __forceinline__ size_t hbm_stack_entry(const RtParams &p, const int l
  * if the tile deferred itself (kMode 2; nothing is stored then). */
 template <bool kStats, int kMode>
 __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays,
-                                            float *__restrict__ out,
+                                            const uint32_t *__restrict__ ctl_words, float *__restrict__ out,
                                             float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
                                             Stats<kStats> &st, const int wave, const int my_xcc, const int steal) {
     constexpr bool kMayDefer = kMode == 2;
@@ -1413,7 +1617,8 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
             const int n_alive = __popcll(__builtin_amdgcn_ballot_w64(alive));
             st_wave(st, n_alive <= 16 ? ST_NEAREST_1_16 : n_alive <= 32 ? ST_NEAREST_17_32 : n_alive <= 48 ? ST_NEAREST_33_48 : ST_NEAREST_49_64);
         }
-        nearest_hit_items<kStats, kMode>(p, lds, wlds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, &defer);   /* whole wavefront, converged */
+        if constexpr (kMode == 6) nearest_hit_fast<kStats>(p, lds, ctl_words, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);
+        else nearest_hit_items<kStats, kMode>(p, lds, wlds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, &defer);   /* whole wavefront, converged */
         if (kMayDefer && defer) alive = false;                /* deferred: nothing more to trace, nothing to store */
         st_cycles(st, ST_CYCLES_NEAREST, t_scan);
         const unsigned long long t_winner = st_clock<kStats>();
@@ -1483,7 +1688,9 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
                 const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
-                const bool blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
+                bool blocked;
+                if constexpr (kMode == 6) blocked = in_shade_fast<kStats>(p, lds, ctl_words, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
+                else blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
                 if (kMayDefer && defer) { shade = false; alive = false; }
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
@@ -1597,7 +1804,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
     return defer;
 }
 
-template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false, bool kClusters = false, bool kRoomy = false>
+template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false, bool kClusters = false, bool kRoomy = false, bool kFast = false>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack,
@@ -1617,6 +1824,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * holds a scene of any size the ABI admits -- no capacity limit, and LDS (hence occupancy)
      * is spent on the bounce stack only. */
     const float4 *lds = kGlobalTables ? image : wlds;
+    /* FAST tables: the items' control words are read from the image in global memory (scalar loads) */
+    const uint32_t *__restrict__ ctl_words = reinterpret_cast<const uint32_t *>(image) + (kFast ? p.fast_ctl_off : 0);
     /* HELP: the clustered-scene kernels get the workgroups' ray areas where the others get the defer list */
     constexpr bool kHelp = kClusters && !kMayDefer && !kSecondPass;
     float4 *help_rays = kHelp ? reinterpret_cast<float4 *>(defer_list) : nullptr;
@@ -1672,7 +1881,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             const int pop = __builtin_amdgcn_readfirstlane(next_pop);
             if (pop >= n_deferred) break;
             if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-            (void)render_tile<kStats, 3>(p, lds, wlds, nullptr, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
+            (void)render_tile<kStats, 3>(p, lds, wlds, nullptr, nullptr, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
         }
         if (lane == 0) coop[RT_COOP_CMD] = make_float4(__uint_as_float(0u), 0.0f, 0.0f, 0.0f);     /* exit */
         __syncthreads();
@@ -1739,7 +1948,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         continue;
     }
     const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
-    if (render_tile<kStats, kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
+    if (render_tile<kStats, kFast ? 6 : kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
         /* the tile deferred itself: the second pass renders it */
         if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
     }
@@ -1785,6 +1994,15 @@ extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
 rt_render_kernel(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                  unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                  unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
+    render_body<false, false, false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+}
+
+/* the same over the two item tables: option "fast" = 0, and option "cull" = 0 (the plain in-order scans) */
+extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
+rt_render_kernel_items(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
+                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                       unsigned int *__restrict__ defer_list) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
@@ -1853,6 +2071,14 @@ rt_render_kernel_stats(const RtParams p_in_kernarg, const float4 *__restrict__ i
                        unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<true, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
+}
+
+extern "C" __global__ void __launch_bounds__(512)
+rt_render_kernel_fast_stats(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
+                            unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
+                            unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
+    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
+    render_body<true, false, false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
 }
 
 extern "C" __global__ void __launch_bounds__(512)

@@ -87,6 +87,9 @@
  * Scene indices */
 #define RT_KIND_SPHERE_LEAF 10
 #define RT_AA_QUADS 2
+/* bit 4 of an item's first word: the item is a finite plane, whose box is padded for a plane's rounding only
+ * and whose slack in the wavefront culls is RT_PLANE_SLACK of the distance instead of RT_SPHERE_SLACK */
+#define RT_ITEM_TIGHT 16u
 
 #define RT_MAX_GEOM_QUADS 65535   /* 16-bit geometry offset in objinfo */
 #define RT_MAX_MATERIALS  4095    /* 12-bit material row in objinfo    */
@@ -161,6 +164,26 @@ typedef struct RtParams {
     int32_t desk_off, help_rays_quads;
     int32_t help_leaves;                 /* a shadow scan with this many candidate leaves asks for help (RT_HELP_LEAVES; option "help") */
     int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
+    /* FAST tables (scenes without clustered sphere runs, option "fast"): see below */
+    int32_t n_fast_items, n_fast_shadow; /* items in all; the first n_fast_shadow are the shadow scan's */
+    int32_t fast_box_off, fast_rec_off;  /* quad offsets: 2 box quads and 2 record quads per item */
+    int32_t fast_ctl_off;                /* u32 offset (4 per quad): one control word per item */
 } RtParams;
+
+/* FAST tables.  Scenes without clustered sphere runs (the reference's built-in Scene: 32 objects) are walked
+ * through ONE item list that serves both scans: first the objects of the shadow scan (the non-light objects of
+ * the scan range), then the others; within each part sorted by kind.  Neither scan depends on the order: the
+ * shadow verdict is an OR (src/RayTracer.cpp:727-729), the nearest hit the minimum of (distance, Scene index)
+ * (:71-80).  Per item i:
+ *   box      2 quads {lo.xyz, bits(kind | RT_ITEM_TIGHT)}, {hi.xyz, control word}: what the wavefront culls test
+ *   record   2 quads, all the exact test reads, so that a candidate costs ONE LDS round trip:
+ *              sphere          {c.xyz, r^2}, {-}
+ *              infinite plane  {n.xyz, distance_to_origin}, {-}
+ *              AA rectangle    {dto, sn, sa, sb}, {origin_a, origin_b, extent_a, extent_b}   (as RT_KIND_FINITE_AA)
+ *              finite plane    {n.xyz, distance_to_origin}, {bits(quad offset of its full record), -, -, -}
+ *   control  one u32: kind | Scene index << 8, read with a SCALAR load from the image in global memory (the
+ *            wavefront's dispatch on the kind and the index for ties never touch a vector register) */
+#define RT_FAST_BOX_QUADS 2
+#define RT_FAST_REC_QUADS 2
 
 #endif /* RT_TABLES_H_ */
