@@ -459,15 +459,18 @@ int pack_scene(rt_scene *s) {
          * of the coordinates involved: 1e-4 of the box's magnitude (500 ulp) covers the part that scales with
          * where the rectangle is, the kernel's RT_PLANE_SLACK the part that scales with the distance travelled;
          * such items carry RT_ITEM_TIGHT.  (With the sphere padding a 14-unit wall was 0.28 thick and, e.g., a
-         * light 0.01 in front of it made it a candidate of every shadow scan towards that light.) */
+         * light 0.01 in front of it made it a candidate of every shadow scan towards that light; at 2e-5 of the
+         * magnitude (170 ulp) a plane is not even a candidate of the shadow rays that START on it, 1e-3 in front
+         * of it -- src/SceneFinitePlane.h:11 --, in scenes up to a few tens of units across.) */
         auto box_item = [&](std::vector<Quad> &out, const double lo[3], const double hi[3], uint32_t bits,
                             uint32_t word1, bool unbounded) {
             double ext = 0.0, mag = 0.0;
             for (int k = 0; k < 3; ++k) {
+                if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) continue;       /* an axis the item is unbounded on */
                 ext = std::max(ext, hi[k] - lo[k]);
                 mag = std::max(mag, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
             }
-            const double pad = 1e-4 + 1e-4 * mag + ((bits & RT_ITEM_TIGHT) ? 0.0 : 1e-2 * ext);
+            const double pad = (bits & RT_ITEM_TIGHT) ? 2e-5 + 2e-5 * mag : 1e-4 + 1e-4 * mag + 1e-2 * ext;
             Quad q0, q1;
             for (int k = 0; k < 3; ++k) {
                 const bool ok = !unbounded && std::isfinite(lo[k]) && std::isfinite(hi[k]) && std::isfinite(pad);
@@ -489,8 +492,17 @@ int pack_scene(rt_scene *s) {
                 for (int k = 0; k < 3; ++k) { lo[k] = (double)o.origin[k] - r; hi[k] = (double)o.origin[k] + r; }
                 box_item(out, lo, hi, (uint32_t)RT_KIND_SPHERE | (full << 16), word1, false);
             } else if (o.kind == RT_KIND_INFINITE_PLANE) {
-                for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = 0.0; }
-                box_item(out, lo, hi, (uint32_t)RT_KIND_INFINITE_PLANE | (full << 16), word1, true);
+                /* An infinite plane whose normal is a +-unit axis vector is a SLAB: bounded on that axis (at
+                 * x_k = -dto * sign: sign * x_k + dto = 0), unbounded on the others, and tight like a finite
+                 * plane -- the hit point's k component is t d_k + o_k with t = (-dto - o_k sign) / (d_k sign)
+                 * (src/SceneInfinitePlane.cpp:40-55), off the plane by a few ulp of |o_k - x_k| + |x_k|.  Any
+                 * other infinite plane is unbounded on every axis: a candidate of every scan. */
+                float sign = 0.0f;
+                const int axis = (s->tight_planes && std::isfinite(o.distance_to_origin)) ? unit_axis(o.normal, &sign) : -1;
+                for (int k = 0; k < 3; ++k) { lo[k] = -(double)INF; hi[k] = (double)INF; }
+                if (axis >= 0) lo[axis] = hi[axis] = -(double)o.distance_to_origin * (double)sign;
+                box_item(out, lo, hi, (uint32_t)RT_KIND_INFINITE_PLANE | (axis >= 0 ? (uint32_t)RT_ITEM_TIGHT : 0u) | (full << 16),
+                         word1, axis < 0);
             } else {
                 /* The hit region is {p on the plane : 0 <= (p-po).h <= h_dist, 0 <= (p-po).v <= v_dist}
                  * (src/SceneFinitePlane.cpp:117-124).  h and v need be neither orthogonal to each

@@ -73,6 +73,21 @@ __device__ __forceinline__ V3 normalize3(const V3 v) {
  * result is the reference's either way. */
 __device__ __forceinline__ V3 renormalize3(const V3 v);
 
+/* Slack of an item's box in the nearest-hit culls, per axis, from the distances `far_k` between the origin box
+ * and the item box's far side on axis k.  Sphere-like items: RT_SPHERE_SLACK of the L1 distance on every axis
+ * (box_needed()).  Plane items (RT_ITEM_TIGHT): RT_PLANE_SLACK of the distance on THAT axis -- component k of the
+ * hit point is t d_k + o_k, rounded twice -- which is also what lets an item be unbounded on some axes (an
+ * axis-aligned infinite plane is a slab: far_k = inf there gives an infinite slack, i.e. no constraint). */
+#define RT_CULL_SLACK(bits, fx, fy, fz, ex, ey, ez)                                                  \
+    do {                                                                                             \
+        const bool tight_ = ((bits) & RT_ITEM_TIGHT) != 0u;                                          \
+        const float sum_ = ((fx) + (fy)) + (fz);                                                     \
+        const float k_ = tight_ ? RT_PLANE_SLACK : RT_SPHERE_SLACK;                                  \
+        ex = k_ * (tight_ ? (fx) : sum_) + 1.0e-4f;                                                  \
+        ey = k_ * (tight_ ? (fy) : sum_) + 1.0e-4f;                                                  \
+        ez = k_ * (tight_ ? (fz) : sum_) + 1.0e-4f;                                                  \
+    } while (0)
+
 /* Wave-level "does any active lane need this": a uniform (scalar) branch, so
  * the guarded block costs no exec-mask bookkeeping; lanes that do not need it
  * run it anyway and discard the result. */
@@ -823,10 +838,10 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             float ax = b0.x - omaxx, bx = b1.x - ominx;
             float ay = b0.y - omaxy, by = b1.y - ominy;
             float az = b0.z - omaxz, bz = b1.z - ominz;
-            const float far = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) + fmaxf(fabsf(az), fabsf(bz));
-            /* a plane's hit point is off its ray by rounding only (RT_PLANE_SLACK); a sphere's box has to hold the coarse float test */
-            const float ex = ((__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? RT_PLANE_SLACK : RT_SPHERE_SLACK) * far + 1.0e-4f;
-            ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
+            /* a plane's hit point is off its ray by rounding only; a sphere's box has to hold the coarse float test */
+            float ex, ey, ez;
+            RT_CULL_SLACK(__float_as_uint(b0.w), fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fabsf(ay), fabsf(by)), fmaxf(fabsf(az), fabsf(bz)), ex, ey, ez);
+            ax -= ex; ay -= ey; az -= ez; bx += ex; by += ey; bz += ez;
             /* feasible t: [t_lo, t_hi], starting from [0, 65535 (the reference's infinity) + slack] */
             /* t dmin <= b and t dmax >= a per axis, as lower / upper bounds of t through
              * the multipliers of bound_multipliers(); a NaN product is no bound */
@@ -1392,9 +1407,10 @@ __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4
             float ax = b0.x - omaxx, bx = b1.x - ominx;
             float ay = b0.y - omaxy, by = b1.y - ominy;
             float az = b0.z - omaxz, bz = b1.z - ominz;
-            const float far = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) + fmaxf(fabsf(az), fabsf(bz));
-            const float ex = ((__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? RT_PLANE_SLACK : RT_SPHERE_SLACK) * far + 1.0e-4f;
-            ax -= ex; ay -= ex; az -= ex; bx += ex; by += ex; bz += ex;
+            /* a plane's hit point is off its ray by rounding only; a sphere's box has to hold the coarse float test */
+            float ex, ey, ez;
+            RT_CULL_SLACK(__float_as_uint(b0.w), fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fabsf(ay), fabsf(by)), fmaxf(fabsf(az), fabsf(bz)), ex, ey, ez);
+            ax -= ex; ay -= ey; az -= ez; bx += ex; by += ey; bz += ez;
             const float t_lo = fmaxf(fmaxf(fmaxf(0.0f, fmaxf(bx * lax, ax * lbx)), fmaxf(by * lay, ay * lby)), fmaxf(bz * laz, az * lbz));
             const float t_hi = fminf(fminf(fminf(65600.0f, fminf(bx * hax, ax * hbx)), fminf(by * hay, ay * hby)), fminf(bz * haz, az * hbz));
             const bool empty = (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi)) || (t_hi < -1.0e-6f);
