@@ -1356,7 +1356,10 @@ __device__ __forceinline__ void fast_item_distance(const RtParams &p, const floa
 }
 
 /* getCollision (src/RayTracer.cpp:50-89) over the FAST item list; the cull and the nearest-first order are
- * nearest_hit_items()'s (see there for why they are exact) */
+ * nearest_hit_items()'s (see there for why they are exact), written for few instructions per scan: the cull always
+ * runs (a bundle whose directions point everywhere gets no bound from it: every item a candidate with entry
+ * distance 0, taken in lane order), candidates are always taken by their entry distance, whose tolerance is already
+ * in the key, and what is the same for the whole wavefront is kept in 64-bit lane masks (scalar registers). */
 template <bool kStats>
 __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4 *lds, const uint32_t *__restrict__ ctl_words,
                                                  const bool active, const V3 o, const V3 d, const bool have_origin_box,
@@ -1367,75 +1370,48 @@ __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4
     st_lane(st, ST_NEAREST_RAYS, active);
     st_wave(st, ST_WAVE_NEAREST);
     const int lane = (int)(threadIdx.x & 63u);
-    const float inf = __builtin_huge_valf();
     const int n_items = p.n_fast_items;
-
-    float dminx = -inf, dmaxx = inf, dminy = -inf, dmaxy = inf, dminz = -inf, dmaxz = inf;
-    bool cull = n_items >= RT_NEAR_CULL_MIN_ITEMS;
-    if (cull) {
-        V3 dlo, dhi;
-        wave_bounds3(d, active, &dlo, &dhi);
-        dminx = dlo.x; dminy = dlo.y; dminz = dlo.z; dmaxx = dhi.x; dmaxy = dhi.y; dmaxz = dhi.z;
-        cull = !((dminx < 0.0f && dmaxx > 0.0f) && (dminy < 0.0f && dmaxy > 0.0f) && (dminz < 0.0f && dmaxz > 0.0f));
-        if (!cull) st_wave(st, ST_NEAREST_UNCULLED);
-    }
-    float ominx = 0, omaxx = 0, ominy = 0, omaxy = 0, ominz = 0, omaxz = 0;
-    float lax = 0, hax = 0, lbx = 0, hbx = 0, lay = 0, hay = 0, lby = 0, hby = 0, laz = 0, haz = 0, lbz = 0, hbz = 0;
-    if (cull) {
-        if (have_origin_box) {
-            ominx = origins_lo.x; ominy = origins_lo.y; ominz = origins_lo.z;
-            omaxx = origins_hi.x; omaxy = origins_hi.y; omaxz = origins_hi.z;
-        } else {
-            V3 olo, ohi;
-            wave_bounds3(o, active, &olo, &ohi);
-            ominx = olo.x; ominy = olo.y; ominz = olo.z; omaxx = ohi.x; omaxy = ohi.y; omaxz = ohi.z;
-        }
-        bound_multipliers(dminx, dmaxx, &lax, &hax, &lbx, &hbx);
-        bound_multipliers(dminy, dmaxy, &lay, &hay, &lby, &hby);
-        bound_multipliers(dminz, dmaxz, &laz, &haz, &lbz, &hbz);
-    }
-    const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
     const float4 *boxes = lds + p.fast_box_off;
     const float4 *recs = lds + p.fast_rec_off;
+    const unsigned long long active_mask = __builtin_amdgcn_ballot_w64(active);
+
+    V3 dlo, dhi, olo = origins_lo, ohi = origins_hi;
+    wave_bounds3(d, active, &dlo, &dhi);
+    if (!have_origin_box) wave_bounds3(o, active, &olo, &ohi);      /* the eye for primary rays, else the previous level's shading points */
+    float lax, hax, lbx, hbx, lay, hay, lby, hby, laz, haz, lbz, hbz;
+    bound_multipliers(dlo.x, dhi.x, &lax, &hax, &lbx, &hbx);
+    bound_multipliers(dlo.y, dhi.y, &lay, &hay, &lby, &hby);
+    bound_multipliers(dlo.z, dhi.z, &laz, &haz, &lbz, &hbz);
+    const bool finite_rays = (__builtin_amdgcn_ballot_w64(!ray_is_finite(o, d)) & active_mask) == 0ull;
 
     for (int base = 0; base < n_items; base += 64) {
-        unsigned long long mask;
-        uint32_t key = 0xFFFFFFFFu;
-        if (cull) {
+        uint32_t key;                      /* this lane's item: tolerant bundle entry distance (high bits) | lane */
+        {
             const int mine = min(base + lane, n_items - 1);
             const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
-            float ax = b0.x - omaxx, bx = b1.x - ominx;
-            float ay = b0.y - omaxy, by = b1.y - ominy;
-            float az = b0.z - omaxz, bz = b1.z - ominz;
-            /* a plane's hit point is off its ray by rounding only; a sphere's box has to hold the coarse float test */
+            float ax = b0.x - ohi.x, bx = b1.x - olo.x;
+            float ay = b0.y - ohi.y, by = b1.y - olo.y;
+            float az = b0.z - ohi.z, bz = b1.z - olo.z;
             float ex, ey, ez;
             RT_CULL_SLACK(__float_as_uint(b0.w), fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fabsf(ay), fabsf(by)), fmaxf(fabsf(az), fabsf(bz)), ex, ey, ez);
             ax -= ex; ay -= ey; az -= ez; bx += ex; by += ey; bz += ez;
             const float t_lo = fmaxf(fmaxf(fmaxf(0.0f, fmaxf(bx * lax, ax * lbx)), fmaxf(by * lay, ay * lby)), fmaxf(bz * laz, az * lbz));
             const float t_hi = fminf(fminf(fminf(65600.0f, fminf(bx * hax, ax * hbx)), fminf(by * hay, ay * hby)), fminf(bz * haz, az * hbz));
-            const bool empty = (t_lo - 1.0e-4f * fabsf(t_lo) - 1.0e-6f > t_hi + 1.0e-4f * fabsf(t_hi)) || (t_hi < -1.0e-6f);
+            /* the entry distance less the tolerance of this arithmetic: what `best` is compared with below.
+             * 0 (also: anything that rounds to it) = the origin box meets the item's box: always tested, see nearest_hit_items() */
+            const float entry = fmaxf(t_lo - 1.0e-4f * t_lo - 1.0e-6f, 0.0f);
+            const bool empty = (entry > t_hi + 1.0e-4f * fabsf(t_hi)) || (t_hi < -1.0e-6f);
             const bool candidate = base + lane < n_items && !empty;
-            mask = __builtin_amdgcn_ballot_w64(candidate);
-            if (candidate) key = (__float_as_uint(t_lo) & ~63u) | (uint32_t)lane;
-        } else {
-            const int left = n_items - base;
-            mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            key = candidate ? ((__float_as_uint(entry) & ~63u) | (uint32_t)lane) : 0xFFFFFFFFu;
         }
-        const bool ordered = cull && __popcll(mask) >= RT_ORDER_MIN_CANDIDATES;
-        while (mask != 0ull) {
-            int src;
-            if (ordered) {
-                const uint32_t nearest_key = wave_min_u32(key);
-                if (nearest_key == 0xFFFFFFFFu) break;
-                src = (int)(nearest_key & 63u);
-                const float entry = __uint_as_float(nearest_key & ~63u);
-                if (entry > 0.0f && !wave_any(active && !(entry - 1.0e-4f * entry - 1.0e-6f > best))) break;
-                if (lane == src) key = 0xFFFFFFFFu;
-                mask &= ~(1ull << src);
-            } else {
-                src = __ffsll((long long)mask) - 1;
-                mask &= mask - 1ull;
-            }
+        for (;;) {
+            const uint32_t nearest_key = wave_min_u32(key);
+            if (nearest_key == 0xFFFFFFFFu) break;                       /* no candidate left */
+            const uint32_t entry_bits = nearest_key & ~63u;
+            /* every ray already has a hit nearer than anything in that box (and in all the remaining ones) */
+            if (entry_bits != 0u && (active_mask & ~__builtin_amdgcn_ballot_w64(__uint_as_float(entry_bits) > best)) == 0ull) break;
+            const int src = (int)(nearest_key & 63u);
+            if (lane == src) key = 0xFFFFFFFFu;
             const int item = base + src;
             const uint32_t ctl = ctl_words[item];
             const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
@@ -1449,36 +1425,36 @@ __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4
     *best_idx_out = active ? best_idx : -1;
 }
 
-/* inShade (src/RayTracer.cpp:709-771) over the first n_fast_shadow items of the FAST list; in_shade()'s cull */
+/* inShade (src/RayTracer.cpp:709-771) over the first n_fast_shadow items of the FAST list; in_shade()'s cull.
+ * The verdict is kept as the smallest blocking distance found so far (-inf for a lane without a shadow ray):
+ * blocked <=> that is below the distance to the light, which is src/RayTracer.cpp:727-729's OR. */
 template <bool kStats>
 __device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *lds, const uint32_t *__restrict__ ctl_words,
                                               const bool active, const V3 o, const V3 d, const float dist_to_light,
                                               const V3 light, const V3 origins_centre, const V3 origins_half, Stats<kStats> &st) {
     const int n_items = p.n_fast_shadow;
-    bool blocked = !active;
     if (n_items == 0) return false;
-    st_lane(st, ST_SHADOW_RAYS, active);
-    st_wave(st, ST_WAVE_SHADOW);
-    const bool cull = n_items >= RT_SHADOW_CULL_MIN_ITEMS;
-    const V3 c = origins_centre;
-    V3 e = origins_half, sinv = mk(0, 0, 0);
-    float grow_more = 0.0f;
-    if (cull) {
-        const V3 seg = sub3(light, c);
-        sinv = approx_inverse(seg);
-        const float reach = (fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (e.x + e.y + e.z);
-        grow_more = uniform_f((RT_SPHERE_SLACK - RT_PLANE_SLACK) * reach);
-        const float grow = RT_PLANE_SLACK * reach + 1.0e-4f;
-        e = mk(uniform_f(e.x + grow), uniform_f(e.y + grow), uniform_f(e.z + grow));
-        sinv = mk(uniform_f(sinv.x), uniform_f(sinv.y), uniform_f(sinv.z));
-    }
-    const int lane = (int)(threadIdx.x & 63u);
-    const bool finite_rays = !wave_any(active && !ray_is_finite(o, d));
     const float4 *boxes = lds + p.fast_box_off;
     const float4 *recs = lds + p.fast_rec_off;
+    st_lane(st, ST_SHADOW_RAYS, active);
+    st_wave(st, ST_WAVE_SHADOW);
+    const float inf = __builtin_huge_valf();
+    float nearest_block = active ? inf : -inf;
+    const V3 c = origins_centre;
+    const V3 seg = sub3(light, c);
+    V3 sinv = approx_inverse(seg);
+    const float reach = (fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (origins_half.x + origins_half.y + origins_half.z);
+    /* the same in every lane: keep them in scalar registers.  `e` carries the slack of a plane item
+     * (RT_ITEM_TIGHT); sphere-like items add `grow_more` */
+    const float grow_more = uniform_f((RT_SPHERE_SLACK - RT_PLANE_SLACK) * reach);
+    const float grow = RT_PLANE_SLACK * reach + 1.0e-4f;
+    const V3 e = mk(uniform_f(origins_half.x + grow), uniform_f(origins_half.y + grow), uniform_f(origins_half.z + grow));
+    sinv = mk(uniform_f(sinv.x), uniform_f(sinv.y), uniform_f(sinv.z));
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool finite_rays = (__builtin_amdgcn_ballot_w64(!ray_is_finite(o, d)) & __builtin_amdgcn_ballot_w64(active)) == 0ull;
     for (int base = 0; base < n_items; base += 64) {
         unsigned long long mask;
-        if (cull) {
+        {
             const int mine = min(base + lane, n_items - 1);
             const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
             const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
@@ -1488,26 +1464,24 @@ __device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *l
             const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
             const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
             const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            /* every comparison is false on a NaN, which then means "candidate" */
             const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
                                (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
             mask = __builtin_amdgcn_ballot_w64(base + lane < n_items && !apart);
-        } else {
-            const int left = n_items - base;
-            mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
         while (mask != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(nearest_block < dist_to_light) == ~0ull) return true;     /* every ray is blocked */
             const int item = base + (__ffsll((long long)mask) - 1);
             mask &= mask - 1ull;
-            if (!wave_any(!blocked)) return true;
             const uint32_t ctl = ctl_words[item];
             const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
             bool hit; float t;
-            fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, dist_to_light, finite_rays, !blocked, &hit, &t, st);
-            blocked = blocked || (hit && t < dist_to_light);
+            fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, dist_to_light, finite_rays, !(nearest_block < dist_to_light), &hit, &t, st);
+            nearest_block = fminf(nearest_block, hit ? t : inf);
         }
     }
-    return blocked;
+    return nearest_block < dist_to_light;
 }
 
 /* Texture_CheckerBoard::getTexturePixel, src/Texture_CheckerBoard.h:31-65.
@@ -1690,12 +1664,18 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
         if (shade) C = mk(0.0f, 0.0f, 0.0f);
         if (wave_any(shade)) {
             /* box of the shading points, shared by every light's shadow scan */
-            have_box = p.cull != 0 && (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS);
-            if (have_box) {
-                wave_bounds3(P, shade, &box_lo, &box_hi);
-            }
             V3 bundle_centre = mk(0, 0, 0), bundle_half = bundle_centre;
-            if (p.cull != 0 && p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
+            if constexpr (kMode == 6) {          /* FAST tables: the culls always run */
+                have_box = true;
+                wave_bounds3(P, shade, &box_lo, &box_hi);
+                shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
+            } else {
+                have_box = p.cull != 0 && (p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS || p.n_near_items >= RT_NEAR_CULL_MIN_ITEMS);
+                if (have_box) {
+                    wave_bounds3(P, shade, &box_lo, &box_hi);
+                }
+                if (p.cull != 0 && p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
+            }
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
