@@ -34,7 +34,7 @@ enum {
     RT_OK = 0,
     RT_ERR_INVALID = 1,      /* bad argument / malformed description        */
     RT_ERR_NO_DEVICE = 2,    /* no usable HIP device                        */
-    RT_ERR_HIP = 3,          /* a HIP runtime call failed                   */
+    RT_ERR_HIP = 3,          /* a HIP runtime call failed, or a kernel reported trouble (see "help_spin_limit") */
     RT_ERR_CAPACITY = 4,     /* more than 4 096 objects, a bounce stack beyond 8 GB, or an LDS option that does not fit */
     RT_ERR_RCCL = 5          /* an RCCL call failed (rt_render_multi)       */
 };
@@ -227,6 +227,21 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   of all, of a GPU's strip of one; 0 = such wavefronts leave;
  *                   2..64 = on, and a scan asks for help from this many candidate
  *                   leaves on (default 8; tests use 2)
+ *   "heavy"         scenes with clustered sphere runs under a horizon (with "help" on): the tiles
+ *                   of the band of tile rows along the horizon line -- each keeps a wavefront
+ *                   busy for a millisecond -- are rendered first, one per WORKGROUP (one
+ *                   wavefront renders, the others share its shadow scans from the first on);
+ *                   -1 (default) = automatic: when the launch renders a strip of at most a
+ *                   third of the image's width (one GPU's share on three or more), a band of
+ *                   0.25 % of the image height either side of the line; 0 = off; k = always,
+ *                   k - 1 tile rows either side
+ *   "help_spin_limit" the bound of an owner's wait for helpers to leave its desk (default
+ *                   2^22 polls); -1 makes every such wait count as timed out: the owner then
+ *                   tests the leaves itself (same pixels), its workgroup stops helping, and
+ *                   the next rt_render / rt_get_timing returns RT_ERR_HIP once (tests)
+ *   "fast"          scenes without clustered runs: 1 (default) = one kind-sorted item list
+ *                   with direct test records (FAST tables), 0 = the two item tables
+ *   "tight_planes"  0 = plane items get the (much larger) padding of sphere items
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
  *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */
 int rt_set_option(rt_scene *scene, const char *key, int value);

@@ -740,6 +740,67 @@ def test_help_on_and_off_render_the_same_strip_of_a_large_frame():
         assert np.array_equal(imgs[0].view(np.uint32), img.view(np.uint32)), what
 
 
+@pytest.mark.parametrize("heavy", [-1, 1, 3, 40])
+@pytest.mark.parametrize("name,W,H,depth,x0,x1", [("grid16", 96, 160, 8, 0, 96), ("grid32", 128, 96, 4, 16, 100), ("grid9", 50, 120, 3, 0, 50)])
+def test_heavy_tiles_do_not_change_results(oracle, name, W, H, depth, x0, x1, heavy):
+    """rt_set_option("heavy", k): the band of tile rows along the horizon line is rendered first, one tile per
+    workgroup, its shadow scans shared with the workgroup's other wavefronts from the first scan on.  Scheduling
+    only: same pixels as the oracle, with the band one row wide, a few rows wide, wider than the image, automatic."""
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    r.set_option("heavy", heavy)
+    r.set_option("help", 2)
+    for _ in range(2):
+        assert_same(r.render(W, H, depth, x0, x1), want[x0:x1], f"{name} heavy {heavy}")
+
+
+def test_heavy_tiles_on_a_tilted_horizon(oracle):
+    """A camera rolled about its viewing axis: the horizon line is slanted, the band follows it column by column."""
+    from scene_gen import build_sphere_field
+    host = build_sphere_field(HostScene.empty(), 3, n_spheres=90)
+    orc = build_sphere_field(oracle.OracleScene(), 3, n_spheres=90)
+    hc = host.camera.contents
+    h = np.array(list(hc.vector_horizontal), dtype=np.float32)
+    v = np.array(list(hc.vector_vertical), dtype=np.float32)
+    ca, sa = np.float32(np.cos(0.3)), np.float32(np.sin(0.3))
+    h2, v2 = ca * h + sa * v, ca * v - sa * h
+    so = np.array(list(hc.screen_origin), dtype=np.float32) + np.float32(0.35) * v       # keep the horizon inside the image
+    for k in range(3):
+        hc.vector_horizontal[k], hc.vector_vertical[k], hc.screen_origin[k] = float(h2[k]), float(v2[k]), float(so[k])
+    orc.cam.vector_horizontal = type(orc.cam.vector_horizontal)(float(h2[0]), float(h2[1]), float(h2[2]))
+    orc.cam.vector_vertical = type(orc.cam.vector_vertical)(float(v2[0]), float(v2[1]), float(v2[2]))
+    orc.cam.screen_origin = type(orc.cam.screen_origin)(float(so[0]), float(so[1]), float(so[2]))
+    want = orc.render(144, 128, 3)
+    r = Renderer(host)
+    r.set_option("help", 2)
+    for heavy in (2, 5, -1):
+        r.set_option("heavy", heavy)
+        assert_same(r.render(144, 128, 3), want, f"tilted horizon, heavy {heavy}")
+        assert_same(r.render(144, 128, 3, 40, 101), want[40:101], f"tilted horizon, heavy {heavy}, strip")
+
+
+def test_help_timeout_path_is_exact_and_reported(oracle):
+    """rt_set_option("help_spin_limit", -1): every wait of an owner for its helpers counts as timed out.  The owner
+    then tests every leaf of the scan itself (an OR: the pixels cannot change), its workgroup stops helping, and
+    the host is told once: RT_ERR_HIP from the call that finds the flag, with the image delivered."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    lib = capi.load_library()
+    name, W, H, depth = "grid16", 96, 80, 8
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    r.set_option("help", 2)
+    r.set_option("block_threads", 256)
+    r.set_option("help_spin_limit", -1)
+    out = np.zeros((W, H, 3), dtype=np.float32)
+    rc = lib.rt_render(r._scene, r._cam, W, H, 0, W, depth, out.ctypes.data)
+    assert rc == capi.RT_ERR_HIP, "the timeout must be reported"
+    assert b"HELP" in lib.rt_last_error()
+    assert_same(out, want, "image of the launch whose HELP waits timed out")
+    r.set_option("help_spin_limit", 1 << 22)
+    assert_same(r.render(W, H, depth), want, "the handle is usable afterwards, and reports nothing")
+
+
 def test_help_option_range():
     from tilecoderaytracer_amd import RtError
     r = Renderer(HostScene.named("grid9"))

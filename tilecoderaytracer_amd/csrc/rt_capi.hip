@@ -105,7 +105,6 @@ float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 struct EventPair { hipEvent_t start, mid, stop; bool pending, two_passes; };
 constexpr int kEventRing = 64;
-constexpr int RT_DESK_WORDS_HOST = 12;   /* RT_DESK_WORDS of rt_kernel.hip */
 constexpr int kCounterWords = (RT_TILE_QUEUES + 1) * RT_QUEUE_STRIDE;   /* 8 queue heads + the second pass's, own cache lines */
 
 } // namespace
@@ -131,6 +130,9 @@ struct rt_scene {
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
     int help_opt = 1;             /* clustered scenes: wavefronts out of tiles help their workgroup's long shadow scans (0: they leave) */
+    int heavy_opt = -1;           /* HEAVY tiles (the band of tile rows along the horizon line, one per workgroup, first): -1 = automatic, 0 = off, k = k - 1 rows either side */
+    int help_spin_opt = RT_HELP_SPIN_LIMIT;   /* the owner's bounded wait at its desk; -1: every wait counts as timed out (tests) */
+    unsigned int *h_error = nullptr;          /* pinned host word the kernels can write: a HELP wait timed out */
     int pairs_opt = 1;            /* scenes with clustered runs: the kernel that compacts (ray, leaf) pairs (0: the plain kernel) */
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int second_block_opt = 0;     /* threads per workgroup of the second pass: 0 = as the first pass, else 64..512 */
@@ -747,26 +749,39 @@ int drain_event(rt_scene *s, int i) {
  * Starting just below the horizon row (image centre column) puts them first:
  * 15 % on the 1 024-sphere grid frame, more on the strips of a multi-GPU frame.
  * Without clustered runs the natural order (bottom row first) is kept. */
+/* the height dz (fraction of the image, may lie outside [0, 1]) at which the pixel column at dx looks along infinite
+ * plane `o`: its rays graze the plane there -- the plane's horizon line; false if the column never does */
+bool horizon_dz(const rt_object_desc &o, const rt_camera_desc *cam, double dx, double *dz) {
+    /* direction of the pixel at (dx, dz) (src/Camera.cpp:71-84), dotted with n: A + B dz */
+    double a = 0.0, b = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const double at_dx = (double)cam->screen_origin[c] +
+                             (double)cam->vector_horizontal[c] * (dx * cam->screen_width - cam->screen_halfwidth) -
+                             (double)cam->vector_vertical[c] * cam->screen_halfheight - (double)cam->eye_origin[c];
+        a += at_dx * o.normal[c];
+        b += (double)cam->vector_vertical[c] * cam->screen_height * o.normal[c];
+    }
+    if (!(std::fabs(b) > 0.0) || !std::isfinite(a / b)) return false;
+    *dz = -a / b;
+    return true;
+}
+
+/* the infinite plane whose horizon line crosses the image's centre column lowest (nullptr: none does) */
+const rt_object_desc *horizon_plane(const rt_scene *s, const rt_camera_desc *cam, double *dz_centre) {
+    const rt_object_desc *best = nullptr;
+    for (const rt_object_desc &o : s->objects) {
+        double dz;
+        if (o.kind != RT_KIND_INFINITE_PLANE || !horizon_dz(o, cam, 0.5, &dz)) continue;
+        if (dz > 0.0 && dz < 1.0 && (!best || dz < *dz_centre)) { best = &o; *dz_centre = dz; }
+    }
+    return best;
+}
+
 int horizon_start(const rt_scene *s, const rt_camera_desc *cam) {
     if (s->n_clusters <= 0) return 0;
-    double best = -1.0;
-    for (const rt_object_desc &o : s->objects) {
-        if (o.kind != RT_KIND_INFINITE_PLANE) continue;
-        /* direction of the centre column's pixel at height dz in [0,1] (src/Camera.cpp:71-84), dotted with n: A + B dz */
-        double a = 0.0, b = 0.0;
-        for (int c = 0; c < 3; ++c) {
-            const double centre = (double)cam->screen_origin[c] +
-                                  (double)cam->vector_horizontal[c] * (0.5 * cam->screen_width - cam->screen_halfwidth) -
-                                  (double)cam->vector_vertical[c] * cam->screen_halfheight - (double)cam->eye_origin[c];
-            a += centre * o.normal[c];
-            b += (double)cam->vector_vertical[c] * cam->screen_height * o.normal[c];
-        }
-        if (!(std::fabs(b) > 0.0)) continue;
-        const double dz = -a / b;
-        if (dz > 0.0 && dz < 1.0 && (best < 0.0 || dz < best)) best = dz;
-    }
-    if (best < 0.0) return 0;
-    return std::max(0, (int)(best * 1000.0) - 8);
+    double dz = 0.0;
+    if (!horizon_plane(s, cam, &dz)) return 0;
+    return std::max(0, (int)(dz * 1000.0) - 8);
 }
 
 /* Workgroup size and where the bounce stack goes.  The stack is 16 B per level
@@ -803,6 +818,16 @@ int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, in
     *stack_lds_levels = (int)in_lds;
     *lds_bytes = (int)((double)scene_bytes + in_lds * per_level);
     if (*lds_bytes < 16) *lds_bytes = 16;
+    return RT_OK;
+}
+
+/* what a finished kernel told the host: reported once, by the first synchronous point that sees it */
+int device_report(rt_scene *s) {
+    if (s->h_error && *reinterpret_cast<volatile unsigned int *>(s->h_error) != 0u) {
+        *s->h_error = 0u;
+        return fail(RT_ERR_HIP, "a wavefront's wait for the helpers at its workgroup's desk timed out (HELP): the image is complete "
+                                "and exact (the owner tested the leaves itself), but this should never happen");
+    }
     return RT_OK;
 }
 
@@ -924,12 +949,43 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.help_leaves = s->help_opt >= 2 ? s->help_opt : RT_HELP_LEAVES;
     if (clusters_kernel && s->help_opt && block > 64) {
         const int desk_off = p.stack_off + stack_lds_levels * block;
-        const int with_desk = (desk_off + (RT_DESK_WORDS_HOST * 4 + 15) / 16) * 16;
+        const int with_desk = (desk_off + (RT_DESK_WORDS * 4 + 15) / 16) * 16;
         if ((size_t)with_desk <= RT_MAX_LDS_BYTES) {
             p.desk_off = desk_off;
             p.help_rays_quads = 128;
             lds_bytes = with_desk;
             s->launch.lds_bytes = lds_bytes;
+        }
+    }
+    /* HEAVY tiles (rt_kernel.hip, render_body): with HELP on, the band of tile rows along the horizon line */
+    p.heavy_half = -1;
+    p.heavy_row0_q16 = p.heavy_slope_q16 = 0;
+    p.help_spin_limit = s->help_spin_opt;
+    p.error_word = (uint64_t)(uintptr_t)s->h_error;
+    /* automatic: only when the launch renders a strip of at most a third of the image's width -- one GPU's share on three
+     * or more.  There the strip waits for its horizon tiles (4096^2, 1 024-sphere grid, longest of 8 strips: 1.39 -> 1.05 ms
+     * with the band, 4 strips 1.68 -> 1.63 ms); a whole frame has enough other tiles to run beside them, and giving three
+     * of a workgroup's four wavefronts to one tile only costs it throughput (4.83 -> 5.02 ms; with a band of 0.9 % of the
+     * height 5.32 ms).  profiles/r03_experiments.txt */
+    const bool heavy_wanted = s->heavy_opt > 0 || (s->heavy_opt < 0 && (long long)(x1 - x0) * 3 <= (long long)W);
+    if (p.help_rays_quads != 0 && heavy_wanted) {
+        double dz_centre = 0.0;
+        if (const rt_object_desc *plane = horizon_plane(s, cam, &dz_centre)) {
+            /* tile row (as a real number) of the line at the centre of tile column c: linear in c */
+            auto row_at = [&](double c, double *row) {
+                double dz;
+                if (!horizon_dz(*plane, cam, ((double)x0 + (c + 0.5) * tile_x) / (double)W, &dz)) return false;
+                *row = dz * (double)H / (double)tile_z;
+                return true;
+            };
+            double r0, r1;
+            const double c1 = (double)std::max<long long>(tiles_x - 1, 1);
+            if (row_at(0.0, &r0) && row_at(c1, &r1) && std::fabs(r0) < 30000.0 && std::fabs(r1) < 30000.0) {
+                p.heavy_half = s->heavy_opt > 0 ? s->heavy_opt - 1
+                                                : (int)std::ceil((double)RT_HEAVY_PERMILLE10 * 1e-4 * (double)H / (double)tile_z);
+                p.heavy_row0_q16 = (int)std::floor(r0 * 65536.0);
+                p.heavy_slope_q16 = (int)std::lround((r1 - r0) / c1 * 65536.0);
+            }
         }
     }
     const bool clusters_wide = (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
@@ -1083,6 +1139,12 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (device < 0 || device >= ndev) { delete s; return fail(RT_ERR_INVALID, "device index out of range"); }
     rc = upload_scene(s);
     if (rc) { rt_scene_destroy(s); return rc; }
+    {
+        /* one word of pinned host memory for what a kernel has to tell the host (a HELP wait that timed out) */
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&s->h_error), sizeof(unsigned int), hipHostMallocDefault);
+        if (e != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+        *s->h_error = 0u;
+    }
     *out = s;
     return RT_OK;
 }
@@ -1098,6 +1160,7 @@ int rt_scene_destroy(rt_scene *s) {
     if (s->d_defer) (void)hipFree(s->d_defer);
     if (s->d_help) (void)hipFree(s->d_help);
     if (s->d_stack) (void)hipFree(s->d_stack);
+    if (s->h_error) (void)hipHostFree(s->h_error);
     delete s;
     return RT_OK;
 }
@@ -1141,7 +1204,7 @@ int rt_render(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int 
         (void)hipEventDestroy(t1);
     }
     HIP_TRY(hipDeviceSynchronize());
-    return RT_OK;
+    return device_report(s);
 }
 
 int rt_render_stats(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth,
@@ -1195,7 +1258,7 @@ int rt_get_timing(const rt_scene *cs, rt_timing *out) {
         }
     }
     *out = s->timing;
-    return RT_OK;
+    return device_report(s);
 }
 
 int rt_reset_timing(rt_scene *s) {
@@ -1251,6 +1314,16 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "help")) {
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "help must be 0 (off), 1 (on) or a number of candidate leaves, [2, 64]");
         s->help_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "heavy")) {
+        if (value < -1 || value > 4096) return fail(RT_ERR_INVALID, "heavy must be -1 (automatic), 0 (off) or 1 + the band's half-width in tile rows");
+        s->heavy_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "help_spin_limit")) {
+        if (value < -1) return fail(RT_ERR_INVALID, "help_spin_limit must be >= -1");
+        s->help_spin_opt = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "pairs")) {

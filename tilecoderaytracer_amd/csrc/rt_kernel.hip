@@ -532,10 +532,8 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
  * strip of it --, when a few tiles with scans over the whole scene are all that is left and most wavefronts
  * would idle.  Nobody ever waits for a helper to ARRIVE; the owner's wait for helpers to LEAVE is bounded by
  * one leaf's tests (and by RT_HELP_SPIN_LIMIT, after which the kernel gives up helping for good). */
-enum { RT_DESK_STATE = 0, RT_DESK_CURSOR, RT_DESK_INSIDE, RT_DESK_FINISHED, RT_DESK_MASK_LO, RT_DESK_MASK_HI,
-       RT_DESK_BASE, RT_DESK_VERDICT_LO, RT_DESK_VERDICT_HI, RT_DESK_BROKEN, RT_DESK_WORDS = 12 };
 enum { RT_DESK_FREE = 0, RT_DESK_FILLING = 1, RT_DESK_OPEN = 2, RT_DESK_CLOSING = 3 };
-#define RT_HELP_SPIN_LIMIT (1 << 22)
+static_assert(ST_COUNT == 25, "RT_STATS_COUNT in include/rt_capi.h must equal ST_COUNT");
 
 /* the desk's words are read and written with workgroup-scope atomics on the LDS pointer itself (ds_read / ds_write that
  * the compiler may neither cache nor move); a volatile generic pointer turned them into flat loads */
@@ -1161,7 +1159,8 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
             if constexpr (kHelped) {                                 /* HELP, above near_leaf_share() */
                 uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
-                if (p.help_rays_quads != 0 && __popcll(leaf_mask) >= p.help_leaves && desk_read(desk, RT_DESK_FINISHED) != 0u &&
+                if (p.help_rays_quads != 0 && __popcll(leaf_mask) >= p.help_leaves &&
+                    (desk_read(desk, RT_DESK_FINISHED) != 0u || desk_read(desk, RT_DESK_DEDICATED) != 0u) &&
                     desk_read(desk, RT_DESK_BROKEN) == 0u) {
                     int mine = 0;
                     if (lane == 0) mine = atomicCAS(desk + RT_DESK_STATE, (uint32_t)RT_DESK_FREE, (uint32_t)RT_DESK_FILLING) == (uint32_t)RT_DESK_FREE;
@@ -1183,15 +1182,30 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                         blocked = help_shadow_candidates<kStats>(lds, items, desk, base, leaf_mask, blocked, o, d, inv, dist_to_light, st);
                         if (lane == 0) desk_write(desk, RT_DESK_STATE, (uint32_t)RT_DESK_CLOSING);
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      /* CLOSING is out before INSIDE is read */
-                        int spins = 0;
-                        while (desk_read(desk, RT_DESK_INSIDE) != 0u && spins < RT_HELP_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(2); ++spins; }
-                        if (spins >= RT_HELP_SPIN_LIMIT) {
-                            if (lane == 0) desk_write(desk, RT_DESK_BROKEN, 1u);                 /* cannot happen; never hang on it */
+                        /* (a helper that arrives now finds the desk CLOSING and leaves at once without touching the verdict) */
+                        bool timed_out = p.help_spin_limit < 0;
+                        for (int spins = 0; !timed_out && desk_read(desk, RT_DESK_INSIDE) != 0u; ++spins) {
+                            if (spins >= p.help_spin_limit) timed_out = true;
+                            else __builtin_amdgcn_s_sleep(2);
                         }
-                        const unsigned long long verdict = (unsigned long long)desk_read(desk, RT_DESK_VERDICT_LO) |
-                                                           ((unsigned long long)desk_read(desk, RT_DESK_VERDICT_HI) << 32);
-                        blocked = blocked || ((verdict >> lane) & 1ull) != 0ull;
-                        if (lane == 0) desk_write(desk, RT_DESK_STATE, (uint32_t)RT_DESK_FREE);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      /* the helpers' verdicts are out before they left */
+                        if (timed_out) {
+                            /* A helper is still inside (cannot happen: it tests one chunk of leaves and leaves) and may hold
+                             * leaves it has not reported: the desk's verdict is incomplete.  Never hang on it and never trust
+                             * it: the owner tests every leaf of the mask itself (an OR: testing a leaf twice changes nothing),
+                             * this workgroup stops helping for good, and the host gets to know (RT_ERR_HIP from the next
+                             * rt_render / rt_get_timing). */
+                            if (lane == 0) {
+                                desk_write(desk, RT_DESK_BROKEN, 1u);
+                                __hip_atomic_store(reinterpret_cast<unsigned int *>(p.error_word), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                            blocked = shadow_leaf_share<kStats>(lds, items, base, leaf_mask, 0, 1, blocked, o, d, inv, dist_to_light, st);
+                        } else {
+                            const unsigned long long verdict = (unsigned long long)desk_read(desk, RT_DESK_VERDICT_LO) |
+                                                               ((unsigned long long)desk_read(desk, RT_DESK_VERDICT_HI) << 32);
+                            blocked = blocked || ((verdict >> lane) & 1ull) != 0ull;
+                            if (lane == 0) desk_write(desk, RT_DESK_STATE, (uint32_t)RT_DESK_FREE);
+                        }
                         mask &= ~leaf_mask;
                     }
                 }
@@ -1914,43 +1928,101 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         }
     }
   } else {
+    /* HEAVY tiles first, one per workgroup: the tiles on the horizon line of a scene with clustered sphere runs keep
+     * ONE wavefront busy for a millisecond or more (their shadow rays start tens of thousands of units away, where
+     * the reference's float sphere test is so coarse that every sphere is a legitimate candidate: 10 scans x 64
+     * leaves x 16 members for all 64 rays), which is what a GPU's strip of a multi-GPU frame then waits for.  The
+     * host names them (a band of tile rows along the horizon line, RtParams::heavy_*); wavefront 0 of a workgroup
+     * renders one at a time while the workgroup's other wavefronts stand at the desk and share every long shadow
+     * scan from the first one on -- the HELP protocol with helpers that are there from the start.  The ordinary
+     * tile queues skip the band.  (One loop hands out both kinds of tile, so that render_tile() is inlined once.) */
+    bool heavy_phase = false;
+    if constexpr (kHelp) {
+        if (p.help_rays_quads != 0 && p.heavy_half >= 0) {
+            uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
+            if ((threadIdx.x >> 6) == 0u) {
+                heavy_phase = true;
+                if (lane == 0) desk_write(desk, RT_DESK_DEDICATED, 1u);
+            } else {
+                for (int spins = 0; spins < RT_HELP_SPIN_LIMIT; ++spins) {
+                    if (desk_read(desk, RT_DESK_PHASE) != 0u || desk_read(desk, RT_DESK_BROKEN) != 0u) break;
+                    if (desk_read(desk, RT_DESK_STATE) != (uint32_t)RT_DESK_OPEN) { __builtin_amdgcn_s_sleep(8); continue; }
+                    serve_desk<kStats>(p, lds, desk, help_rays, st);
+                }
+            }
+        }
+    }
     const int macro_rows = (p.tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
     const int n_macros = macro_rows * p.tiles_x;
-  for (int steal = 0; steal < RT_TILE_QUEUES; ++steal) {
-    const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
-    unsigned int *const head = tile_counter + queue * RT_QUEUE_STRIDE;
-    /* macro tiles queue, queue + 8, queue + 16, ... */
-    const int queue_len = queue < n_macros ? ((n_macros - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
-    int next_pop = 0;
-    if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-   for (;;) {
-    const int pop = __builtin_amdgcn_readfirstlane(next_pop);
-    if (pop >= queue_len) break;
-    /* ask for the following tile now; the answer is only needed after this one is rendered.  Not so in scenes
+    /* ask for the following tile while this one is rendered; the answer is only needed afterwards.  Not so in scenes
      * with clustered sphere runs, whose tiles take from tens of microseconds to milliseconds: a tile asked for
      * ahead of a long one waits for it while other wavefronts idle (a strip's timeline showed tiles STARTING a
      * millisecond after the queues had run dry); there the next tile is asked for when this one is done */
     const bool ask_ahead = !(kClusters || kMayDefer || kStats) || p.n_clusters == 0;     /* the plain kernels: always */
-    if (ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
-    const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
-    const int queued_row = macro / p.tiles_x;
-    const int tile_col = macro - queued_row * p.tiles_x;
-    /* from first_macro_row (< macro_rows) upwards, or (rows_downwards) downwards; both wrap around */
-    const int shifted_row = p.rows_downwards ? p.first_macro_row - queued_row : p.first_macro_row + queued_row;
-    const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : (shifted_row < 0 ? shifted_row + macro_rows : shifted_row);
-    const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
-    if (tile_row >= p.tiles_z) {                            /* ragged top macro row */
-        if (!ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
-        continue;
+    int steal = 0, next_pop = 0;
+    bool fresh = true;                 /* the current queue has not been asked yet */
+    for (;;) {
+        int wave;                      /* tile number, row-major */
+        unsigned int *head = nullptr;
+        if (kHelp && heavy_phase) {
+            unsigned int *const heavy_head = tile_counter + RT_TILE_QUEUES * RT_QUEUE_STRIDE;
+            int h = 0;
+            if (lane == 0) h = (int)atomicAdd(heavy_head, 1u);
+            h = __builtin_amdgcn_readfirstlane(h);
+            if (h >= (2 * p.heavy_half + 1) * p.tiles_x) {              /* the band is done: on to the ordinary tiles */
+                heavy_phase = false;
+                uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
+                if (lane == 0) {
+                    desk_write(desk, RT_DESK_DEDICATED, 0u);
+                    desk_write(desk, RT_DESK_PHASE, 1u);
+                }
+                continue;
+            }
+            /* the rows of the band from the horizon line outwards: 0, +1, -1, +2, -2, ... */
+            const int k = h / p.tiles_x, tile_col = h - k * p.tiles_x;
+            const int offset = (k & 1) ? (k + 1) / 2 : -(k / 2);
+            const int tile_row = ((p.heavy_row0_q16 + tile_col * p.heavy_slope_q16) >> 16) + offset;
+            if (tile_row < 0 || tile_row >= p.tiles_z) continue;
+            wave = tile_row * p.tiles_x + tile_col;
+        } else {
+            if (steal >= RT_TILE_QUEUES) break;
+            const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
+            head = tile_counter + queue * RT_QUEUE_STRIDE;
+            /* macro tiles queue, queue + 8, queue + 16, ... */
+            const int queue_len = queue < n_macros ? ((n_macros - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
+            if (fresh) {
+                if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
+                fresh = false;
+            }
+            const int pop = __builtin_amdgcn_readfirstlane(next_pop);
+            if (pop >= queue_len) { ++steal; fresh = true; continue; }          /* next queue */
+            if (ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
+            const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
+            const int queued_row = macro / p.tiles_x;
+            const int tile_col = macro - queued_row * p.tiles_x;
+            /* from first_macro_row (< macro_rows) upwards, or (rows_downwards) downwards; both wrap around */
+            const int shifted_row = p.rows_downwards ? p.first_macro_row - queued_row : p.first_macro_row + queued_row;
+            const int macro_row = shifted_row >= macro_rows ? shifted_row - macro_rows : (shifted_row < 0 ? shifted_row + macro_rows : shifted_row);
+            const int tile_row = macro_row * RT_MACRO_ROWS + (pop % RT_MACRO_ROWS);
+            bool skip = tile_row >= p.tiles_z;                      /* ragged top macro row */
+            if constexpr (kHelp) {                                  /* a HEAVY tile: rendered by a workgroup, above */
+                if (p.help_rays_quads != 0 && p.heavy_half >= 0) {
+                    const int off_line = tile_row - ((p.heavy_row0_q16 + tile_col * p.heavy_slope_q16) >> 16);
+                    skip = skip || (off_line >= -p.heavy_half && off_line <= p.heavy_half);
+                }
+            }
+            if (skip) {
+                if (!ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
+                continue;
+            }
+            wave = tile_row * p.tiles_x + tile_col;
+        }
+        if (render_tile<kStats, kFast ? 6 : kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
+            /* the tile deferred itself: the second pass renders it */
+            if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
+        }
+        if (head != nullptr && !ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
     }
-    const int wave = tile_row * p.tiles_x + tile_col;       /* tile number, row-major */
-    if (render_tile<kStats, kFast ? 6 : kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
-        /* the tile deferred itself: the second pass renders it */
-        if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
-    }
-    if (!ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
-   }  /* next tile of this queue */
-  }   /* next queue */
     if constexpr (kHelp) {
         /* HELP: out of tiles -- serve the colleagues until they are, too */
         if (p.help_rays_quads != 0) {
@@ -1990,7 +2062,11 @@ extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
 rt_render_kernel(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
                  unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
                  unsigned int *__restrict__ defer_list) {
+#ifdef RT_FAST_PARAMS_BY_VALUE
+    const RtParams &p = p_in_kernarg;
+#else
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
+#endif
     render_body<false, false, false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
 }
 

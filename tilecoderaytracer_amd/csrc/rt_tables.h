@@ -114,6 +114,11 @@
 #define RT_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)   /* s_getreg_b32 HW_REG_XCC_ID, bits [3:0] */
 
 #define RT_HELP_LEAVES 8
+#define RT_HELP_SPIN_LIMIT (1 << 22)
+#define RT_HEAVY_PERMILLE10 25        /* automatic half-width of the HEAVY band: 0.25 % of the image height (2 tile rows of 4 pixels at 4096) */
+/* the workgroup's HELP desk: words of LDS (rt_kernel.hip) */
+enum { RT_DESK_STATE = 0, RT_DESK_CURSOR, RT_DESK_INSIDE, RT_DESK_FINISHED, RT_DESK_MASK_LO, RT_DESK_MASK_HI,
+       RT_DESK_BASE, RT_DESK_VERDICT_LO, RT_DESK_VERDICT_HI, RT_DESK_BROKEN, RT_DESK_DEDICATED, RT_DESK_PHASE, RT_DESK_WORDS = 12 };
 #ifndef RT_DEFER_LEAVES
 #define RT_DEFER_LEAVES 32           /* automatic: a scan with this many candidate leaves, most of them needed by some ray, defers its tile */
 #endif
@@ -163,11 +168,18 @@ typedef struct RtParams {
      * the launch carries 128 quads of global memory per workgroup for the published rays (0: no helping) */
     int32_t desk_off, help_rays_quads;
     int32_t help_leaves;                 /* a shadow scan with this many candidate leaves asks for help (RT_HELP_LEAVES; option "help") */
+    int32_t help_spin_limit;             /* the owner's bounded wait for helpers to leave its desk (RT_HELP_SPIN_LIMIT; < 0: every wait counts as timed out -- tests) */
+    /* HEAVY tiles (rt_kernel.hip): the tiles within heavy_half tile rows of the horizon line -- tile row
+     * (heavy_row0_q16 + tile column * heavy_slope_q16) >> 16 -- are rendered first, one per WORKGROUP: wavefront 0
+     * renders, the others serve its shadow scans at the desk from the first scan on.  heavy_half < 0: none. */
+    int32_t heavy_half, heavy_row0_q16, heavy_slope_q16;
     int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
     /* FAST tables (scenes without clustered sphere runs, option "fast"): see below */
     int32_t n_fast_items, n_fast_shadow; /* items in all; the first n_fast_shadow are the shadow scan's */
     int32_t fast_box_off, fast_rec_off;  /* quad offsets: 2 box quads and 2 record quads per item */
     int32_t fast_ctl_off;                /* u32 offset (4 per quad): one control word per item */
+    /* one word of host memory the kernel can write (rt_scene's sticky device error): set when a HELP wait timed out */
+    uint64_t error_word;
 } RtParams;
 
 /* FAST tables.  Scenes without clustered sphere runs (the reference's built-in Scene: 32 objects) are walked
