@@ -7,17 +7,23 @@ A "step" is one full render of the workload image.  At N = 1 the whole image
 is one kernel launch on one GPU.  At N > 1 (one process per GPU, launched with
 torch.distributed.run) the image is split into N contiguous x-strips
 (the framebuffer is x-major, pixels[x][z], so a strip is one contiguous
-block), every rank renders its strip into HBM and the strips are gathered to
-rank 0 with RCCL (torch.distributed backend "nccl") -- STRONG scaling: the
-image is fixed, the work per GPU shrinks.  Frames are independent, so the
-gather of frame k (RCCL's stream) overlaps the render of frame k+1 (two strip
-buffers; --no-overlap serialises them).  The strips are cut by measured cost
-(--partition balanced, the default): the first two warm-up steps (two extra
-untimed ones if W < 3) run N equal strips and measure every rank's kernel time
-and the time of a gather on its own; the image is then re-cut so that rank 0 -- which receives and sends
-nothing -- renders as long as a peer needs to render and ship its columns
-(tilecoderaytracer_amd/distributed.py: balanced_bounds).  All W warm-up steps
-are untimed; the K timed steps all run the final partition.
+block), every rank renders its strip into HBM and the strips travel to rank 0
+over RCCL (torch.distributed backend "nccl") -- STRONG scaling: the image is
+fixed, the work per GPU shrinks.  The headline `value` is the SINGLE-FRAME
+figure SURVEY.md 8(d) defines: every frame is rendered and delivered before
+the next one starts.  Within a frame a strip may be rendered and sent in
+column CHUNKS (--chunks; automatic: from the measured kernel and transfer
+times), chunk k on its way while chunk k+1 is rendered, as the reference's
+ranks write into the shared image while they render.  The strips are cut by
+measured cost (--partition balanced, the default): the first two warm-up steps
+(two extra untimed ones if W < 3) run N equal strips and measure every rank's
+kernel time and the time of a gather on its own; the image is then re-cut so
+that rank 0 -- which receives and sends nothing -- renders as long as a peer
+needs to render and ship its columns (tilecoderaytracer_amd/distributed.py:
+balanced_bounds).  All W warm-up steps are untimed; the K timed steps all run
+the final partition.  The throughput of a STREAM of frames (gather of frame k
+under the render of frame k+1) is measured afterwards and reported beside the
+headline as `pipelined`, labelled as a different figure.
 
 Timed region: barrier + synchronize, K steps (kernel + gather), barrier +
 synchronize; MAX over ranks.  The framebuffer stays in HBM (inputs -- the
@@ -26,11 +32,11 @@ is inside it.  value = W*H*K / t  [Mrays/s], primary rays = pixels, the
 reference's own figure of merit (src/RayTracer.cpp:1104, us/pixel inverted).
 
 Extra objects on the JSON line:
-  roofline      the dominant (only) kernel rt_render_kernel against the HBM
-                roofline the north star names: achieved = algorithmic bytes
-                (12 B per pixel: one packed fp32 RGB store) / average kernel
-                duration, measured with HIP events on the launch stream inside
-                the timed region.
+  roofline      the dominant (only) kernel -- its name as launched is in
+                roofline.kernel -- against the HBM roofline the north star
+                names: achieved = algorithmic bytes (12 B per pixel: one packed
+                fp32 RGB store) / average kernel duration, measured with HIP
+                events on the launch stream inside the timed region.
   sphere_grid   (default workload only) the same partition timed on the
                 1024-sphere grid scene, BASELINE.json configs[2], the scene the
                 north star quotes for the 1/2/4/8-GPU series; a few steps, after
@@ -41,6 +47,11 @@ Extra objects on the JSON line:
   cpu_baseline  the CPU oracle (oracle/rt_oracle.c, a port of the reference's
                 algorithm; the reference itself is unbuildable here) timed on
                 this host's cores on a bounded sample of the same workload.
+
+--workload shipped / shipped512 time the drop-in EXECUTABLE end to end instead
+(process start to raytracer_screen.txt on disk: the reference's own Run_Time /
+us/pixel, src/RayTracer.cpp:1089-1104, 1576-1577) beside the CPU oracle doing
+the same job; see shipped_workload().
 """
 import argparse
 import json
@@ -62,6 +73,9 @@ WORKLOADS = {
     "builtin8k":        ("builtin",         8192, 8192, 4, "configs[3]: 8192x8192 tiled one strip per GPU"),
     "twomirrors":       ("twomirrors",      4096, 4096, 50, "not a BASELINE config: the reference's SCENE 2 (3 920 objects, facing mirrors, "
                                                              "src/Scene.cpp:23-206), MAX_RECURSION_LEVEL 50; tables of 119 KB read from global memory"),
+    # the whole drop-in program, process start -> raytracer_screen.txt (shipped_workload())
+    "shipped":          ("builtin",         500, 504, 50, "the reference as shipped: SCREEN 500x504, MAX_RECURSION_LEVEL 50 (src/rt_project_parameters.h:65-66,73)"),
+    "shipped512":       ("builtin",         512, 512, 3, "configs[0]: built-in Scene, 512x512, depth 3, .txt output"),
 }
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -128,6 +142,9 @@ def parse_args():
                          "'equal' keeps N equal strips")
     ap.add_argument("--no-overlap", action="store_true",
                     help="(accepted for compatibility; the headline at N > 1 is always the single-frame figure)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="N > 1, single-frame mode: column chunks a strip is rendered and sent in (chunk k travels while "
+                         "chunk k+1 is rendered); 0 = automatic from the measured kernel and transfer times, 1 = none")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="N > 1: skip the second, pipelined measurement (gather of frame k under the render of frame k+1)")
     return ap.parse_args()
@@ -260,8 +277,87 @@ def cpu_baseline(scene_name, W, H, depth, sample_columns, gpu_image=None, repeat
     }
 
 
+def shipped_workload(args):
+    """The reference's own run: main() renders SCREEN_WIDTH x SCREEN_HEIGHT at MAX_RECURSION_LEVEL and
+    writes raytracer_screen.txt; its figure of merit is Run_Time and us/pixel of the whole program
+    (src/RayTracer.cpp:1089-1104, 1576-1577).  Here: bin/tcrt_raytracer (the drop-in executable: scene,
+    HIP context, render, device-to-host copy, text formatting, file on disk) timed as a process, and
+    the CPU oracle doing the same job in this process (render on one core -- the reference's shipped
+    CORE_NUM 1 -- then the same byte-exact writer), both `steps` times, medians.  One JSON line."""
+    import hashlib
+    import subprocess
+    import tempfile
+    scene_name, W, H, depth, cfg_note = WORKLOADS[args.workload]
+    exe = os.path.join(ROOT, "tilecoderaytracer_amd", "bin", "tcrt_raytracer")
+    if not os.path.exists(exe):
+        sys.exit(f"{exe} not built (make -C tilecoderaytracer_amd/csrc)")
+    steps = max(1, min(args.steps, 10))
+    gpu_wall, gpu_md5 = [], None
+    with tempfile.TemporaryDirectory() as d:
+        out_txt = os.path.join(d, "raytracer_screen.txt")
+        for k in range(args.warmup and 1 or 0):
+            subprocess.run([exe, "--width", str(W), "--height", str(H), "--depth", str(depth), "--out", out_txt],
+                           check=True, capture_output=True)
+        for k in range(steps):
+            t0 = time.perf_counter()
+            subprocess.run([exe, "--width", str(W), "--height", str(H), "--depth", str(depth), "--out", out_txt],
+                           check=True, capture_output=True)
+            gpu_wall.append(time.perf_counter() - t0)
+        body = b"".join(open(out_txt, "rb").readlines()[10:])           # the pixel lines (the header carries the timing)
+        gpu_md5 = hashlib.md5(body).hexdigest()
+        gpu_bytes = os.path.getsize(out_txt)
+        # the CPU oracle doing the same job: render (one core), then the same writer
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib  # noqa: E402  (the checker, timed beside the product)
+            from tilecoderaytracer_amd import host as host_mod
+            scene = oracle_lib.OracleScene.named(scene_name)
+            cpu_wall = []
+            cpu_txt = os.path.join(d, "cpu_screen.txt")
+            for k in range(min(steps, 3)):
+                t0 = time.perf_counter()
+                img = scene.render(W, H, depth)
+                t1 = time.perf_counter()
+                host_mod.write_screen_txt(cpu_txt, img, run_time_s=t1 - t0)
+                cpu_wall.append((time.perf_counter() - t0, t1 - t0))
+            cpu_body = b"".join(open(cpu_txt, "rb").readlines()[10:])
+            cpu = {"wall_s": round(float(np.median([w for w, _ in cpu_wall])), 4),
+                   "render_s": round(float(np.median([r for _, r in cpu_wall])), 4),
+                   "us_per_pixel": round(float(np.median([w for w, _ in cpu_wall])) / (W * H) * 1e6, 4),
+                   "cores": 1, "kind": "port",
+                   "pixel_lines_md5": hashlib.md5(cpu_body).hexdigest(),
+                   "what": "oracle/rt_oracle.c on one core (the reference's shipped CORE_NUM 1) + the same .txt writer, in this process"}
+    wall = float(np.median(gpu_wall))
+    out = {
+        "metric": "Mrays/sec of the whole drop-in program (process start to raytracer_screen.txt on disk); the reference's Run_Time / us/pixel",
+        "value": round(W * H / wall / 1e6, 4),
+        "unit": "Mrays/s",
+        "n_gpus": 1, "steps": steps, "warmup": 1 if args.warmup else 0,
+        "ms_per_step": round(wall * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (hard-coded reference scene; no files)",
+        "config": {"workload": f"bin/tcrt_raytracer, {scene_name} scene, {W}x{H}, max depth {depth}, .txt output ({gpu_bytes} bytes)",
+                   "baseline_config": cfg_note,
+                   "us_per_pixel": round(wall / (W * H) * 1e6, 4),
+                   "runs_s": [round(w, 4) for w in gpu_wall],
+                   "pixel_lines_md5": gpu_md5,
+                   "identical_to_cpu_oracle_output": (cpu is not None and cpu["pixel_lines_md5"] == gpu_md5) if cpu else None,
+                   "note": "dominated by process start, HIP context creation and the first kernel load; the kernel itself is "
+                           "microseconds at this size (the N = 1 default workload is the kernel figure)"},
+        "roofline": None,
+        "cpu_baseline": ({"value": round(W * H / cpu["wall_s"] / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                          "sample": f"the whole {W}x{H} job, median of {min(steps, 3)} runs", **cpu} if cpu else None),
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.workload in ("shipped", "shipped512"):
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+            sys.exit("the shipped workloads time one process on one GPU")
+        return shipped_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -316,14 +412,18 @@ def main():
         for kv in args.option:
             k, v = kv.split("=")
             renderer.set_option(k, int(v))
-        def make_pipe(bounds=None):
+        def make_pipe(bounds=None, chunks=1):
             pp = StripPipeline(W, H, world, rank, dev, render=None, overlap=overlap,
-                               force_gather=args.force_dist, bounds=bounds)
-            a, b = pp.x0, pp.x1
-            pp.render = lambda buf: renderer.render_device(W, H, depth, a, b, buf.data_ptr(), stream)
+                               force_gather=args.force_dist, bounds=bounds, chunks=chunks, align=16)
+            x0_, x1_ = pp.x0, pp.x1
+            # whole strip, or (chunked) columns [a, b) of it into the matching part of the strip buffer
+            pp.render = lambda buf, a=None, b=None: renderer.render_device(
+                W, H, depth, x0_ if a is None else a, x1_ if b is None else b, buf.data_ptr(), stream)
             return pp
 
-        pipe = make_pipe()
+        # chunks: given, or decided with the partition below (automatic); one GPU: only if asked for
+        chunks = args.chunks if (args.chunks > 0 and not overlap) else 1
+        pipe = make_pipe(chunks=chunks if world == 1 else 1)
 
         def fence():
             pipe.drain()
@@ -336,6 +436,8 @@ def main():
         # re-cut (tilecoderaytracer_amd.distributed.balanced_bounds) and the warm-up continues.
         partition_note = None
         warm_left = warmup
+        if world > 1 and args.partition != "balanced":
+            pipe = make_pipe(chunks=chunks)
         if world > 1 and args.partition == "balanced":
             pipe.step()
             fence()
@@ -346,14 +448,16 @@ def main():
             my_kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
             bounds = None
             try:
-                bounds, partition_note = measure_and_balance(pipe, W, my_kernel_ms, fence, dev, overlap=overlap)
+                bounds, partition_note = measure_and_balance(pipe, W, my_kernel_ms, fence, dev, overlap=overlap,
+                                                             chunks=0 if (args.chunks == 0 and not overlap) else chunks)
+                chunks = measure_and_balance.last_chunks
             except Exception as e:                                         # never lose the run to the tuning step
                 partition_note = f"balanced partition unavailable ({e!r}); equal strips"
             # all ranks take the new strips, or none does
             ok = torch.tensor([1 if bounds is not None else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok[0]) == 1:
-                pipe = make_pipe(bounds)
+                pipe = make_pipe(bounds, chunks)
             elif bounds is not None:
                 partition_note = "balanced partition failed on another rank; equal strips"
             warm_left = max(warmup - 2, 1)       # at least one untimed frame on the final partition (first use of the links)
@@ -460,7 +564,7 @@ def main():
                 "baseline_config": cfg_note,
                 "objects": host.object_count,
                 "partition": m["partition"] + (
-                    ", RCCL gather to rank 0 after the kernel (single frame: max-rank kernel + gather)" if world > 1 else ""),
+                    ", RCCL transfers to rank 0 (single frame: every frame is delivered before the next starts)" if world > 1 else ""),
                 "partition_note": m["partition_note"],
                 "block_threads": li.block_threads,
                 "lds_bytes_per_block": li.lds_bytes,
@@ -470,7 +574,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "rt_render_kernel",
+                "kernel": li.kernel.decode() if isinstance(li.kernel, bytes) else str(li.kernel),
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -144,6 +144,26 @@ int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, int W, int H,
 int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
                     int max_depth, int ngpu, float *out_rgb);
 
+/* The same with everything that can survive from frame to frame kept in a handle: the per-GPU
+ * scenes, two streams per GPU, the strip buffers, the image on device 0 and the RCCL communicator
+ * (rt_render_multi = create + render + destroy).  rt_multi_render renders and sends every strip in
+ * `chunks` column chunks (1..64): chunk k travels to device 0 on the GPU's communication stream
+ * (ncclSend / ncclRecv) while its compute stream renders chunk k+1 -- within one frame, the way the
+ * reference's ranks write into the shared `pixels` while they render (src/RayTracer.cpp:904-923,
+ * 1188-1193).  Every chunk is a kernel launch of its own: 1 is right where a strip's kernel is long
+ * next to its transfer, 4..8 where the transfer is as long as the kernel (the built-in scene). */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **out);
+int rt_multi_render(rt_multi *multi, const rt_camera_desc *cam, int W, int H, int max_depth,
+                    int chunks, float *out_rgb);
+int rt_multi_set_option(rt_multi *multi, const char *key, int value);   /* rt_set_option on every GPU's scene */
+int rt_multi_destroy(rt_multi *multi);
+
+/* Chunk k of `chunks` column chunks of columns [x0, x1): [*a, *b), about equal widths, inner
+ * boundaries a multiple of `align` columns from x0 (trailing chunks may be empty).  Returns 0, or
+ * 1 on bad arguments. */
+int rt_chunk_bounds(int x0, int x1, int chunks, int k, int align, int *a, int *b);
+
 /* The partition rt_render_multi uses: strip g of ngpu equal x-strips of ceil(W / ngpu) columns is
  * columns [*x0, *x1) (trailing strips may be short or empty); returns the strip width, which is also
  * the column stride of the strips in the gathered buffer (rank g at g * width: only trailing strips

@@ -3,7 +3,7 @@
 # usage: scripts/gpu.sh 'bash scripts/iter.sh <tag> [variant names for ab_gpu.py, default: r2 main]'
 T=${1:-it}
 shift || true
-V=${@:-r2 main}
+V=${@:-main}
 mkdir -p gpurun_out
 python3 -m pytest tests -m gpu -x -q > gpurun_out/${T}_tests.log 2>&1
 rc=$?

@@ -39,3 +39,31 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     sec = j["secondary"]
     assert sec["rays_per_pixel"] > 1.0 and sec["total_rays_per_s"] > j["value"] * 1e6
     assert 0.0 < sec["test_flop_frac_of_valu_peak"] < 1.0
+    assert r["kernel"] == "rt_render_kernel"
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_runs_the_chunked_single_frame_path_on_one_gpu():
+    """--force-dist: torch.distributed over RCCL with one rank; --chunks 4: every frame in four column-chunk launches."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--force-dist", "--chunks", "4",
+                          "--no-cpu-baseline", "--no-extra", "--workload", "grid16d8", "--size", "512"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert "4 column chunks" in j["config"]["partition"] and j["value"] > 10.0
+    assert j["roofline"]["kernel"].startswith("rt_render_kernel_clusters")
+
+
+@pytest.mark.gpu
+def test_bench_shipped_workload_times_the_executable_end_to_end():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "shipped512", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["config"]["pixel_lines_md5"] == "ee680aed641062c6f3a5e0b3fba94199"       # SURVEY.md App. D: the reference's 512x512 d3 text body
+    assert j["config"]["identical_to_cpu_oracle_output"] is True
+    assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["us_per_pixel"] > 0 and j["config"]["us_per_pixel"] > 0

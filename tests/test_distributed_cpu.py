@@ -173,6 +173,98 @@ def test_uneven_strips_reach_rank0_in_place(oracle, bounds, overlap):
     np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_chunk_bounds_cover_a_strip_and_match_the_c_abi():
+    """distributed.chunk_bounds and rt_chunk_bounds (csrc/rt_multi.hip) are the same arithmetic: chunks are
+    contiguous, in order, cover [x0, x1) exactly, and inner boundaries lie a multiple of `align` from x0."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    from tilecoderaytracer_amd.distributed import chunk_bounds
+    lib = capi.load_library()
+    for x0, x1 in ((0, 4096), (512, 1024), (100, 612), (7, 7), (3, 8), (0, 37), (1000, 1001), (16, 48)):
+        for chunks in (1, 2, 3, 4, 8, 64):
+            for align in (1, 4, 16):
+                got = chunk_bounds(x0, x1, chunks, align)
+                assert len(got) == chunks and got[0][0] == x0 and got[-1][1] == x1
+                for k, (a, b) in enumerate(got):
+                    assert x0 <= a <= b <= x1
+                    assert k == 0 or a == got[k - 1][1]
+                    assert b == x1 or (b - x0) % align == 0
+                    ca, cb = C.c_int(), C.c_int()
+                    assert lib.rt_chunk_bounds(x0, x1, chunks, k, align, C.byref(ca), C.byref(cb)) == 0
+                    assert (ca.value, cb.value) == (a, b)
+    assert lib.rt_chunk_bounds(0, 8, 0, 0, 1, None, None) == 1 and lib.rt_chunk_bounds(0, 8, 2, 2, 1, None, None) == 1
+
+
+def _chunked_worker(rank, world, W, H, bounds, chunks, align, init_file, out_file):
+    """The single-frame mode with column chunks: render chunk k, start its transfer, render chunk k+1."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle_lib
+    from tilecoderaytracer_amd.distributed import StripPipeline
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    scene = oracle_lib.OracleScene.builtin()
+    frame = {"d": 0, "calls": []}
+
+    def render(buf, a, b):
+        assert buf.shape[0] == b - a and b > a
+        buf.copy_(torch.from_numpy(scene.render(W, H, frame["d"] % 3, a, b)))
+        frame["calls"].append((a, b))
+
+    pipe = StripPipeline(W, H, world, rank, "cpu", render, overlap=False, bounds=bounds, chunks=chunks, align=align)
+    for _ in range(3):
+        frame["calls"] = []
+        pipe.step()
+        frame["d"] += 1
+        # this rank's chunks: in order, contiguous, exactly its strip
+        cols = [x for a, b in frame["calls"] for x in range(a, b)]
+        assert cols == list(range(pipe.x0, pipe.x1))
+        assert len(frame["calls"]) <= chunks
+    img = pipe.image(W)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_file, img.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,bounds,chunks,align", [
+    (2, 64, None, 4, 4),                                     # equal strips, chunks of 8 columns
+    (2, 37, None, 3, 4),                                     # widths that do not divide
+    (3, 30, [(0, 20), (20, 25), (25, 30)], 4, 4),            # uneven strips: a peer with fewer tiles than chunks (empty chunks)
+    (3, 30, [(0, 11), (11, 11), (11, 30)], 2, 16),           # an empty strip; a strip narrower than the alignment
+    (3, 30, [(0, 0), (0, 17), (17, 30)], 8, 1),              # rank 0 renders nothing
+])
+def test_chunked_single_frame_delivers_the_image(oracle, world, W, bounds, chunks, align):
+    H = 12
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.npy")
+        mp.spawn(_chunked_worker, args=(world, W, H, bounds, chunks, align, init_file, out_file), nprocs=world, join=True)
+        got = np.load(out_file)
+    ref = oracle.OracleScene.builtin().render(W, H, 2 % 3)      # the 3rd frame
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_balanced_bounds_with_chunks():
+    """Chunked single-frame cost: between the pipelined and the serial model; more chunks, wider peer strips."""
+    from tilecoderaytracer_amd.distributed import balanced_bounds, suggest_chunks
+    cost, g = np.full(4096, 1.08 / 4096), 2.68 / 4096
+
+    def frame_time(b, K):
+        t = []
+        for r, (x0, x1) in enumerate(b):
+            R, S = (x1 - x0) * 1.08 / 4096, (x1 - x0) * g
+            t.append(R if r == 0 else (R + S if K == 1 else max(R, S) + min(R, S) / K))
+        return max(t)
+    times = []
+    for K in (1, 2, 4, 8):
+        b = balanced_bounds(4096, 8, cost, g, overlap=False, chunks=K)
+        assert b[0][0] == 0 and b[-1][1] == 4096 and all(b[r][1] == b[r + 1][0] for r in range(7))
+        times.append(frame_time(b, K))
+    assert times[0] > times[1] > times[2] > times[3]
+    pipelined = balanced_bounds(4096, 8, cost, g, overlap=True)
+    assert times[3] > max([(pipelined[0][1] - pipelined[0][0]) * 1.08 / 4096] + [(x1 - x0) * g for x0, x1 in pipelined[1:]]) - 1e-9
+    assert suggest_chunks(0.2, 0.34) >= 4 and suggest_chunks(1.2, 0.1) == 1 and suggest_chunks(0.0, 0.0) == 1
+
+
 def _balance_worker(rank, world, W, H, init_file, out_file):
     """bench.py's N > 1 warm-up: equal partition, measure, re-cut, carry on."""
     sys.path.insert(0, ROOT)

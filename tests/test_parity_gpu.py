@@ -316,6 +316,32 @@ def test_render_multi_single_gpu(oracle):
     assert rc == capi.RT_ERR_INVALID
 
 
+def test_multi_handle_renders_frames_in_column_chunks(oracle):
+    """rt_multi_create / rt_multi_render / rt_multi_destroy: scenes, streams, buffers (and, beyond one GPU, the
+    communicator) persist across frames; every frame is rendered in `chunks` launches whose column chunks land in
+    place.  One GPU is all this box has: the transfers are then nothing, the chunked renders and the handle are
+    what is exercised -- sizes, depths and chunk counts change from frame to frame on the same handle."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    lib = capi.load_library()
+    for name in ("builtin", "grid9"):
+        host, orc = HostScene.named(name), oracle.OracleScene.named(name)
+        m = C.c_void_p()
+        capi.check(lib.rt_multi_create(host.desc, 1, C.byref(m)))
+        try:
+            capi.check(lib.rt_multi_set_option(m, b"help", 2))
+            for W, H, depth, chunks in ((50, 30, 3, 1), (200, 64, 4, 4), (37, 19, 2, 8), (200, 64, 4, 64), (16, 16, 1, 3)):
+                out = np.zeros((W, H, 3), dtype=np.float32)
+                capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, chunks, out.ctypes.data))
+                assert_same(out, orc.render(W, H, depth), f"{name} {W}x{H} d{depth} in {chunks} chunks")
+            out = np.zeros((8, 8, 3), dtype=np.float32)
+            assert lib.rt_multi_render(m, host.camera, 8, 8, 1, 0, out.ctypes.data) == capi.RT_ERR_INVALID
+            assert lib.rt_multi_render(m, host.camera, 8, 8, 1, 65, out.ctypes.data) == capi.RT_ERR_INVALID
+        finally:
+            capi.check(lib.rt_multi_destroy(m))
+    assert lib.rt_multi_create(host.desc, 64, C.byref(m)) == capi.RT_ERR_INVALID      # more GPUs than the box has
+
+
 def test_host_executable_writes_the_reference_log(oracle, tmp_path):
     """tcrt_raytracer = the reference's main(): default run writes raytracer_screen.txt."""
     import subprocess

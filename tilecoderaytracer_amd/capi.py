@@ -103,6 +103,11 @@ def load_library():
     lib.rt_render_multi.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), i, i, i, i, vp]
     lib.rt_strip_bounds.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.rt_strip_bounds.restype = i
+    lib.rt_chunk_bounds.argtypes = [i, i, i, i, i, C.POINTER(i), C.POINTER(i)]
+    lib.rt_multi_create.argtypes = [C.POINTER(RtSceneDesc), i, C.POINTER(vp)]
+    lib.rt_multi_render.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, vp]
+    lib.rt_multi_set_option.argtypes = [vp, C.c_char_p, i]
+    lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_render_stats.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, C.POINTER(C.c_uint64), i, vp, i]
     lib.rt_get_timing.argtypes = [vp, C.POINTER(RtTiming)]
     lib.rt_reset_timing.argtypes = [vp]
@@ -110,7 +115,8 @@ def load_library():
     lib.rt_set_option.argtypes = [vp, C.c_char_p, i]
     for name in ("rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render",
                  "rt_render_device", "rt_render_multi", "rt_render_stats", "rt_get_timing", "rt_reset_timing",
-                 "rt_get_launch_info", "rt_set_option"):
+                 "rt_get_launch_info", "rt_set_option", "rt_chunk_bounds", "rt_multi_create", "rt_multi_render",
+                 "rt_multi_set_option", "rt_multi_destroy"):
         getattr(lib, name).restype = i
     _lib = lib
     return lib

@@ -10,6 +10,13 @@
  * place, no repacking.  dx/dz are computed from the global x and W, H, so the
  * gathered image is bit-identical to a single-GPU render.
  *
+ * Within a frame every strip is rendered and sent in column CHUNKS: chunk k
+ * travels to device 0 on the device's communication stream while chunk k+1 is
+ * rendered on its compute stream -- the reference's ranks, too, write their
+ * pixels into the shared image while they render (src/RayTracer.cpp:904-923,
+ * 1188-1193); there is no serial "then gather" phase.  rt_multi_create() keeps
+ * the scenes, streams, buffers and the communicator across frames.
+ *
  * RCCL is bound lazily (dlopen of librccl.so) so that the single-GPU entry
  * points carry no RCCL dependency; per-process multi-GPU (bench.py, one rank
  * per GPU) uses torch.distributed's RCCL instead and never calls this.
@@ -35,7 +42,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Gather)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -57,7 +65,8 @@ bool load_rccl(Rccl &r, std::string &err) {
     BIND(CommDestroy, "ncclCommDestroy");
     BIND(GroupStart, "ncclGroupStart");
     BIND(GroupEnd, "ncclGroupEnd");
-    BIND(Gather, "ncclGather");
+    BIND(Send, "ncclSend");
+    BIND(Recv, "ncclRecv");
     BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
     return true;
@@ -76,104 +85,194 @@ extern "C" int rt_strip_bounds(int W, int ngpu, int g, int *x0, int *x1) {
     return strip;
 }
 
-extern "C" int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
-                               int max_depth, int ngpu, float *out_rgb) {
-    if (!desc || !cam || !out_rgb) return rt_internal_set_error(RT_ERR_INVALID, "desc/cam/out_rgb is NULL");
-    if (W <= 0 || H <= 0 || ngpu <= 0) return rt_internal_set_error(RT_ERR_INVALID, "W, H, ngpu must be positive");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return rt_internal_set_error(RT_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
-    if (ngpu > ndev) return rt_internal_set_error(RT_ERR_INVALID, "ngpu exceeds the visible devices");
+extern "C" int rt_chunk_bounds(int x0, int x1, int chunks, int k, int align, int *a, int *b) {
+    if (x0 < 0 || x1 < x0 || chunks <= 0 || k < 0 || k >= chunks || align <= 0) return 1;
+    const long long n = (long long)x1 - x0, units = (n + align - 1) / align;
+    const long long lo = (units * k / chunks) * align, hi = (units * (k + 1) / chunks) * align;
+    if (a) *a = x0 + (int)(lo < n ? lo : n);
+    if (b) *b = x0 + (int)(hi < n ? hi : n);
+    return 0;
+}
 
-    /* equal strips of ceil(W / ngpu) columns; trailing strips may be short or
-     * empty.  Because only trailing strips are short, columns [0, W) are
-     * contiguous at the start of the gathered buffer. */
-    const int strip = rt_strip_bounds(W, ngpu, 0, nullptr, nullptr);
-    const size_t strip_floats = (size_t)strip * (size_t)H * 3;
-
-    std::vector<rt_scene *> scenes((size_t)ngpu, nullptr);
-    std::vector<void *> d_strip((size_t)ngpu, nullptr);
-    std::vector<hipStream_t> streams((size_t)ngpu, nullptr);
-    std::vector<ncclComm_t> comms((size_t)ngpu, nullptr);
-    void *d_full = nullptr;
+/* the multi-GPU handle: everything that survives from frame to frame */
+struct rt_multi {
+    int ngpu = 0;
+    std::vector<rt_scene *> scenes;
+    std::vector<hipStream_t> compute, comm;          /* per device: the render kernels' stream and the transfers' */
+    std::vector<std::vector<hipEvent_t>> rendered;   /* per device, per chunk: that chunk's kernel is done */
+    std::vector<void *> d_strip;                     /* per device g >= 1: its strip, strip_floats floats */
+    std::vector<size_t> strip_bytes;
+    std::vector<ncclComm_t> comms;
+    void *d_full = nullptr;                          /* device 0: the whole image; device 0 renders its strip in place */
+    size_t full_bytes = 0;
     Rccl rccl;
-    int rc = RT_OK;
-    std::string err;
+};
 
-    auto cleanup = [&]() {
-        for (int g = 0; g < ngpu; ++g) {
-            (void)hipSetDevice(g);
-            if (comms[(size_t)g] && rccl.CommDestroy) rccl.CommDestroy(comms[(size_t)g]);
-            if (streams[(size_t)g]) (void)hipStreamDestroy(streams[(size_t)g]);
-            if (d_strip[(size_t)g]) (void)hipFree(d_strip[(size_t)g]);
-            if (scenes[(size_t)g]) rt_scene_destroy(scenes[(size_t)g]);
-        }
-        if (d_full) { (void)hipSetDevice(0); (void)hipFree(d_full); }
-        if (rccl.handle) dlclose(rccl.handle);
-    };
-#define HIP_OR_BAIL(expr)                                                             \
+namespace {
+
+int multi_fail(int code, const std::string &msg) { return rt_internal_set_error(code, msg.c_str()); }
+
+#define HIP_OR_FAIL(expr)                                                             \
     do {                                                                              \
         hipError_t e_ = (expr);                                                       \
-        if (e_ != hipSuccess) {                                                       \
-            err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
-            cleanup();                                                                \
-            return rt_internal_set_error(RT_ERR_HIP, err.c_str());                    \
-        }                                                                             \
+        if (e_ != hipSuccess) return multi_fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
-#define NCCL_OR_BAIL(expr)                                                            \
+#define NCCL_OR_FAIL(m, expr)                                                         \
     do {                                                                              \
         ncclResult_t r_ = (expr);                                                     \
-        if (r_ != 0) {                                                                \
-            err = std::string(#expr) + ": " + rccl.GetErrorString(r_);                \
-            cleanup();                                                                \
-            return rt_internal_set_error(RT_ERR_RCCL, err.c_str());                   \
-        }                                                                             \
+        if (r_ != 0) return multi_fail(RT_ERR_RCCL, std::string(#expr) + ": " + (m)->rccl.GetErrorString(r_)); \
     } while (0)
 
-    for (int g = 0; g < ngpu; ++g) {
-        rc = rt_scene_create(desc, g, &scenes[(size_t)g]);
-        if (rc) { cleanup(); return rc; }
-        HIP_OR_BAIL(hipSetDevice(g));
-        HIP_OR_BAIL(hipStreamCreate(&streams[(size_t)g]));
-        HIP_OR_BAIL(hipMalloc(&d_strip[(size_t)g], strip_floats * sizeof(float)));
-    }
-    HIP_OR_BAIL(hipSetDevice(0));
-    HIP_OR_BAIL(hipMalloc(&d_full, strip_floats * sizeof(float) * (size_t)ngpu));
+constexpr int kMaxChunks = 64;
 
+} // namespace
+
+extern "C" int rt_multi_destroy(rt_multi *m) {
+    if (!m) return RT_OK;
+    for (int g = 0; g < m->ngpu; ++g) {
+        (void)hipSetDevice(g);
+        if ((size_t)g < m->comms.size() && m->comms[(size_t)g] && m->rccl.CommDestroy) m->rccl.CommDestroy(m->comms[(size_t)g]);
+        if ((size_t)g < m->rendered.size())
+            for (hipEvent_t e : m->rendered[(size_t)g]) (void)hipEventDestroy(e);
+        if ((size_t)g < m->compute.size() && m->compute[(size_t)g]) (void)hipStreamDestroy(m->compute[(size_t)g]);
+        if ((size_t)g < m->comm.size() && m->comm[(size_t)g]) (void)hipStreamDestroy(m->comm[(size_t)g]);
+        if ((size_t)g < m->d_strip.size() && m->d_strip[(size_t)g]) (void)hipFree(m->d_strip[(size_t)g]);
+        if ((size_t)g < m->scenes.size() && m->scenes[(size_t)g]) rt_scene_destroy(m->scenes[(size_t)g]);
+    }
+    if (m->d_full) { (void)hipSetDevice(0); (void)hipFree(m->d_full); }
+    if (m->rccl.handle) dlclose(m->rccl.handle);
+    delete m;
+    return RT_OK;
+}
+
+extern "C" int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **out) {
+    if (!desc || !out) return multi_fail(RT_ERR_INVALID, "desc/out is NULL");
+    *out = nullptr;
+    if (ngpu <= 0) return multi_fail(RT_ERR_INVALID, "ngpu must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return multi_fail(RT_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
+    if (ngpu > ndev) return multi_fail(RT_ERR_INVALID, "ngpu exceeds the visible devices");
+    rt_multi *m = new (std::nothrow) rt_multi();
+    if (!m) return multi_fail(RT_ERR_INVALID, "out of memory");
+    m->ngpu = ngpu;
+    m->scenes.assign((size_t)ngpu, nullptr);
+    m->compute.assign((size_t)ngpu, nullptr);
+    m->comm.assign((size_t)ngpu, nullptr);
+    m->rendered.assign((size_t)ngpu, {});
+    m->d_strip.assign((size_t)ngpu, nullptr);
+    m->strip_bytes.assign((size_t)ngpu, 0);
+    m->comms.assign((size_t)ngpu, nullptr);
+    auto bail = [&](int rc) { rt_multi_destroy(m); return rc; };
+    for (int g = 0; g < ngpu; ++g) {
+        int rc = rt_scene_create(desc, g, &m->scenes[(size_t)g]);
+        if (rc) return bail(rc);
+        hipError_t e = hipSetDevice(g);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->compute[(size_t)g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->comm[(size_t)g], hipStreamNonBlocking);
+        if (e != hipSuccess) return bail(multi_fail(RT_ERR_HIP, std::string("stream setup: ") + hipGetErrorString(e)));
+    }
     if (ngpu > 1) {
-        if (!load_rccl(rccl, err)) { cleanup(); return rt_internal_set_error(RT_ERR_RCCL, err.c_str()); }
+        std::string err;
+        if (!load_rccl(m->rccl, err)) return bail(multi_fail(RT_ERR_RCCL, err));
         std::vector<int> devs((size_t)ngpu);
         for (int g = 0; g < ngpu; ++g) devs[(size_t)g] = g;
-        NCCL_OR_BAIL(rccl.CommInitAll(comms.data(), ngpu, devs.data()));
+        ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), ngpu, devs.data());
+        if (r != 0) return bail(multi_fail(RT_ERR_RCCL, std::string("ncclCommInitAll: ") + m->rccl.GetErrorString(r)));
     }
-
-    /* render: every GPU its strip, concurrently, each on its own stream */
-    for (int g = 0; g < ngpu; ++g) {
-        int x0 = 0, x1 = 0;
-        (void)rt_strip_bounds(W, ngpu, g, &x0, &x1);
-        rc = rt_render_device(scenes[(size_t)g], cam, W, H, x0, x1, max_depth, d_strip[(size_t)g],
-                              streams[(size_t)g]);
-        if (rc) { cleanup(); return rc; }
-    }
-    /* gather to rank 0 over xGMI, enqueued behind each strip's kernel */
-    if (ngpu > 1) {
-        NCCL_OR_BAIL(rccl.GroupStart());
-        for (int g = 0; g < ngpu; ++g) {
-            HIP_OR_BAIL(hipSetDevice(g));
-            NCCL_OR_BAIL(rccl.Gather(d_strip[(size_t)g], g == 0 ? d_full : nullptr, strip_floats, kNcclFloat, 0,
-                                     comms[(size_t)g], streams[(size_t)g]));
-        }
-        NCCL_OR_BAIL(rccl.GroupEnd());
-    }
-    for (int g = 0; g < ngpu; ++g) {
-        HIP_OR_BAIL(hipSetDevice(g));
-        HIP_OR_BAIL(hipStreamSynchronize(streams[(size_t)g]));
-    }
-    HIP_OR_BAIL(hipSetDevice(0));
-    const size_t image_bytes = (size_t)W * (size_t)H * 3 * sizeof(float);
-    HIP_OR_BAIL(hipMemcpy(out_rgb, ngpu > 1 ? d_full : d_strip[0], image_bytes, hipMemcpyDeviceToHost));
-    cleanup();
+    *out = m;
     return RT_OK;
-#undef HIP_OR_BAIL
-#undef NCCL_OR_BAIL
+}
+
+extern "C" int rt_multi_set_option(rt_multi *m, const char *key, int value) {
+    if (!m) return multi_fail(RT_ERR_INVALID, "handle is NULL");
+    for (rt_scene *s : m->scenes) {
+        int rc = rt_set_option(s, key, value);
+        if (rc) return rc;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_multi_render(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_depth, int chunks, float *out_rgb) {
+    if (!m || !cam || !out_rgb) return multi_fail(RT_ERR_INVALID, "handle/cam/out_rgb is NULL");
+    if (W <= 0 || H <= 0) return multi_fail(RT_ERR_INVALID, "W and H must be positive");
+    if (chunks <= 0 || chunks > kMaxChunks) return multi_fail(RT_ERR_INVALID, "chunks must be in [1, 64]");
+    const int ngpu = m->ngpu;
+    /* equal strips of ceil(W / ngpu) columns; trailing strips may be short or empty */
+    const int strip = rt_strip_bounds(W, ngpu, 0, nullptr, nullptr);
+    const size_t column_floats = (size_t)H * 3;
+    const size_t image_bytes = (size_t)W * column_floats * sizeof(float);
+    HIP_OR_FAIL(hipSetDevice(0));
+    if (image_bytes > m->full_bytes) {
+        if (m->d_full) { HIP_OR_FAIL(hipFree(m->d_full)); m->d_full = nullptr; m->full_bytes = 0; }
+        HIP_OR_FAIL(hipMalloc(&m->d_full, image_bytes));
+        m->full_bytes = image_bytes;
+    }
+    for (int g = 0; g < ngpu; ++g) {
+        HIP_OR_FAIL(hipSetDevice(g));
+        const size_t need = (size_t)strip * column_floats * sizeof(float);
+        if (g > 0 && need > m->strip_bytes[(size_t)g]) {
+            if (m->d_strip[(size_t)g]) { HIP_OR_FAIL(hipFree(m->d_strip[(size_t)g])); m->d_strip[(size_t)g] = nullptr; m->strip_bytes[(size_t)g] = 0; }
+            HIP_OR_FAIL(hipMalloc(&m->d_strip[(size_t)g], need));
+            m->strip_bytes[(size_t)g] = need;
+        }
+        while ((int)m->rendered[(size_t)g].size() < chunks) {
+            hipEvent_t e;
+            HIP_OR_FAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->rendered[(size_t)g].push_back(e);
+        }
+    }
+    /* chunk boundaries fall on multiples of 16 columns from the strip's first (the widest wavefront tile) */
+    const int align = 16;
+    for (int k = 0; k < chunks; ++k) {
+        /* every GPU renders chunk k of its strip (device 0 straight into the image) ... */
+        for (int g = 0; g < ngpu; ++g) {
+            int x0 = 0, x1 = 0, a = 0, b = 0;
+            (void)rt_strip_bounds(W, ngpu, g, &x0, &x1);
+            (void)rt_chunk_bounds(x0, x1, chunks, k, align, &a, &b);
+            float *dst = g == 0 ? static_cast<float *>(m->d_full) + (size_t)a * column_floats
+                                : static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats;
+            int rc = rt_render_device(m->scenes[(size_t)g], cam, W, H, a, b, max_depth, dst, m->compute[(size_t)g]);
+            if (rc) return rc;
+            HIP_OR_FAIL(hipSetDevice(g));
+            HIP_OR_FAIL(hipEventRecord(m->rendered[(size_t)g][(size_t)k], m->compute[(size_t)g]));
+            HIP_OR_FAIL(hipStreamWaitEvent(m->comm[(size_t)g], m->rendered[(size_t)g][(size_t)k], 0));
+        }
+        /* ... and chunk k goes to device 0 over xGMI, behind its kernel, while chunk k + 1 is rendered */
+        if (ngpu > 1) {
+            NCCL_OR_FAIL(m, m->rccl.GroupStart());
+            for (int g = 1; g < ngpu; ++g) {
+                int x0 = 0, x1 = 0, a = 0, b = 0;
+                (void)rt_strip_bounds(W, ngpu, g, &x0, &x1);
+                (void)rt_chunk_bounds(x0, x1, chunks, k, align, &a, &b);
+                if (b <= a) continue;
+                const size_t count = (size_t)(b - a) * column_floats;
+                NCCL_OR_FAIL(m, m->rccl.Send(static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats, count, kNcclFloat, 0,
+                                             m->comms[(size_t)g], m->comm[(size_t)g]));
+                NCCL_OR_FAIL(m, m->rccl.Recv(static_cast<float *>(m->d_full) + (size_t)a * column_floats, count, kNcclFloat, g,
+                                             m->comms[0], m->comm[0]));
+            }
+            NCCL_OR_FAIL(m, m->rccl.GroupEnd());
+        }
+    }
+    for (int g = 0; g < ngpu; ++g) {
+        HIP_OR_FAIL(hipSetDevice(g));
+        HIP_OR_FAIL(hipStreamSynchronize(m->compute[(size_t)g]));
+        HIP_OR_FAIL(hipStreamSynchronize(m->comm[(size_t)g]));
+    }
+    HIP_OR_FAIL(hipSetDevice(0));
+    HIP_OR_FAIL(hipMemcpy(out_rgb, m->d_full, image_bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
+                               int max_depth, int ngpu, float *out_rgb) {
+    if (!desc || !cam || !out_rgb) return multi_fail(RT_ERR_INVALID, "desc/cam/out_rgb is NULL");
+    if (W <= 0 || H <= 0 || ngpu <= 0) return multi_fail(RT_ERR_INVALID, "W, H, ngpu must be positive");
+    rt_multi *m = nullptr;
+    int rc = rt_multi_create(desc, ngpu, &m);
+    if (rc) return rc;
+    rc = rt_multi_render(m, cam, W, H, max_depth, ngpu > 1 ? 4 : 1, out_rgb);
+    rt_multi_destroy(m);
+    return rc;
 }

@@ -42,7 +42,17 @@ def equal_bounds(W, world):
     return [strip_bounds(W, world, r)[:2] for r in range(world)]
 
 
-def balanced_bounds(W, world, column_cost, send_cost_per_column, root=0, overlap=True):
+def chunk_bounds(x0, x1, chunks, align=1):
+    """[(a, b)] * chunks: columns [x0, x1) cut into `chunks` contiguous column chunks of about equal
+    width (trailing ones may be empty) whose inner boundaries lie a multiple of `align` columns from x0
+    (the kernel's wavefront tiles are `align` columns wide: a chunk then never splits one).  The same
+    arithmetic as rt_chunk_bounds() of the C ABI (csrc/rt_multi.hip)."""
+    n, K, align = max(x1 - x0, 0), max(int(chunks), 1), max(int(align), 1)
+    units = -(-n // align)
+    return [(x0 + min(n, (units * k // K) * align), x0 + min(n, (units * (k + 1) // K) * align)) for k in range(K)]
+
+
+def balanced_bounds(W, world, column_cost, send_cost_per_column, root=0, overlap=True, chunks=1):
     """Contiguous strips, in rank order, that minimise the frame time:
 
         rank `root`:  sum of column_cost over its strip          (it sends nothing)
@@ -51,6 +61,10 @@ def balanced_bounds(W, world, column_cost, send_cost_per_column, root=0, overlap
                       that sum + columns * send_cost_per_column       overlap=False: ONE frame,
                       a peer's columns leave after its kernel (max-rank
                       kernel + gather)
+                      max(R, S) + min(R, S) / chunks                   overlap=False, chunks > 1: ONE
+                      frame whose strip is rendered and sent in `chunks` column chunks, chunk k on its
+                      way while chunk k + 1 is rendered (R = that sum, S = the send term): only the
+                      first chunk of the slower activity is not covered by the other
 
     column_cost[x] is the (measured) render time of image column x on one GPU,
     send_cost_per_column the (measured) time one peer needs to deliver one column
@@ -68,21 +82,32 @@ def balanced_bounds(W, world, column_cost, send_cost_per_column, root=0, overlap
     g = max(float(send_cost_per_column), 0.0)
     prefix = np.concatenate([[0.0], np.cumsum(cost)])
 
+    K = max(int(chunks), 1)
+
+    def rank_time(r, x, x1):
+        render = prefix[x1] - prefix[x]
+        if r == root or g <= 0.0:
+            return render
+        send = g * (x1 - x)
+        if overlap:
+            return max(render, send)
+        if K <= 1:
+            return render + send
+        return max(render, send) + min(render, send) / K
+
     def fill(limit):
         bounds, x = [], 0
         for r in range(world):
-            # furthest x1 with prefix[x1] - prefix[x] <= limit
-            if r != root and g > 0.0 and not overlap:
-                # render + send <= limit: prefix[x1] + g * x1 <= prefix[x] + g * x + limit (monotone in x1)
-                serial = prefix + g * np.arange(W + 1)
-                x1 = int(np.searchsorted(serial, serial[x] + limit, side="right")) - 1
-            else:
-                x1 = int(np.searchsorted(prefix, prefix[x] + limit, side="right")) - 1
-            x1 = max(x, min(W, x1))
-            if r != root and g > 0.0 and overlap:
-                x1 = min(x1, x + int(limit / g))
-            bounds.append((x, x1))
-            x = x1
+            # furthest x1 with rank_time(r, x, x1) <= limit (monotone in x1)
+            lo_, hi_ = x, W
+            while lo_ < hi_:
+                mid_ = (lo_ + hi_ + 1) // 2
+                if rank_time(r, x, mid_) <= limit:
+                    lo_ = mid_
+                else:
+                    hi_ = mid_ - 1
+            bounds.append((x, lo_))
+            x = lo_
         return bounds, x
 
     lo, hi = 0.0, float(prefix[-1]) + g * W + 1e-9
@@ -122,7 +147,17 @@ def gather_uneven(strip_buf, views, bounds, dst=0, async_op=False):
     return works
 
 
-def measure_and_balance(pipe, W, my_kernel_ms, sync, device, overlap=True):
+def suggest_chunks(kernel_ms, send_ms, most=8):
+    """Column chunks per strip for the single-frame mode: 1 while a strip's send is short next to its
+    kernel (every chunk is a launch of its own: fewer tiles per launch, a launch gap each), up to `most`
+    where the send is as long as the kernel or longer (the built-in scene: 25 MB over a link against
+    0.2 ms of rendering)."""
+    if kernel_ms <= 0.0:
+        return most if send_ms > 0.0 else 1
+    return int(min(most, max(1, round(4.0 * send_ms / kernel_ms))))
+
+
+def measure_and_balance(pipe, W, my_kernel_ms, sync, device, overlap=True, chunks=1):
     """Called by every rank between two warm-up frames on the EQUAL partition.
     Times one gather on its own (nothing else in flight; `sync()` must drain the
     device and end with a barrier), shares every rank's kernel time, and returns
@@ -147,9 +182,13 @@ def measure_and_balance(pipe, W, my_kernel_ms, sync, device, overlap=True):
         if b > a:
             cost[a:b] = max(k, 0.0) / (b - a)
     per_column_send = gather_ms / max(eq[0][1] - eq[0][0], 1)
-    bounds = balanced_bounds(W, world, cost, per_column_send, overlap=overlap)
+    if chunks == 0:                                       # automatic: from what was just measured, the same on every rank
+        chunks = suggest_chunks(float(np.mean(kernel_by_rank)), gather_ms) if not overlap else 1
+    bounds = balanced_bounds(W, world, cost, per_column_send, overlap=overlap, chunks=chunks)
     note = (f"re-cut after warm-up frames on the equal partition: kernel ms per rank "
-            f"{[round(k, 3) for k in kernel_by_rank]}, gather alone {gather_ms:.3f} ms")
+            f"{[round(k, 3) for k in kernel_by_rank]}, gather alone {gather_ms:.3f} ms"
+            + (f"; every strip rendered and sent in {chunks} column chunks" if chunks > 1 else ""))
+    measure_and_balance.last_chunks = chunks
     return bounds, note
 
 
@@ -164,12 +203,20 @@ class StripPipeline:
     """
 
     def __init__(self, W, H, world, rank, device, render, overlap=True, dtype=torch.float32, force_gather=False,
-                 bounds=None):
+                 bounds=None, chunks=1, align=1):
         self.world, self.rank, self.render, self.overlap = world, rank, render, overlap
         self.gather = world > 1 or force_gather          # force_gather: run the collective even with one rank
         self.x0, self.x1, self.strip = strip_bounds(W, world, rank)
+        # single-frame mode with chunks > 1: the strip is rendered and sent in column chunks (render(buf, a, b)
+        # per chunk), chunk k on its way to rank 0 while chunk k + 1 is rendered -- within ONE frame, as the
+        # reference's ranks write their pixels into the shared image while they render
+        # (src/RayTracer.cpp:904-923, 1188-1193).  Chunks travel point-to-point, like uneven strips.
+        self.chunks = max(int(chunks), 1) if not overlap else 1
+        self.align = max(int(align), 1)
+        if self.chunks > 1 and bounds is None:
+            bounds = equal_bounds(W, world)
         self.bounds = None                               # None: the equal partition and one gather collective
-        if bounds is not None and list(bounds) != equal_bounds(W, world):
+        if bounds is not None and (list(bounds) != equal_bounds(W, world) or self.chunks > 1):
             assert len(bounds) == world and bounds[0][0] == 0 and bounds[-1][1] == W
             assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
             self.bounds = [tuple(b) for b in bounds]
@@ -198,10 +245,36 @@ class StripPipeline:
                 w.wait()
             self.pending[b] = None
 
+    def _step_chunked(self, buf):
+        """One frame, chunk by chunk: render chunk k, then start its transfer and carry on with chunk k + 1."""
+        per_rank = [chunk_bounds(a, b, self.chunks, self.align) for a, b in self.bounds]
+        works = []
+        for k in range(self.chunks):
+            a, b = per_rank[self.rank][k]
+            if b > a:
+                self.render(buf[a - self.x0:b - self.x0], a, b)
+            if not self.gather:
+                continue
+            ops = []
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    ra, rb = per_rank[r][k]
+                    if rb > ra:
+                        ops.append(dist.P2POp(dist.irecv, self.views[r][ra - self.bounds[r][0]:rb - self.bounds[r][0]], r))
+            elif b > a:
+                ops.append(dist.P2POp(dist.isend, buf[a - self.x0:b - self.x0], 0))
+            if ops:
+                works += dist.batch_isend_irecv(ops)
+        for w in works:
+            w.wait()
+
     def step(self):
         b, slot = self.k % len(self.bufs), self.k % len(self.pending)
         self.k += 1
         self._wait(slot)
+        if self.chunks > 1:
+            self._step_chunked(self.bufs[b])
+            return
         self.render(self.bufs[b])
         if self.gather:
             if self.bounds is None:
@@ -226,4 +299,6 @@ class StripPipeline:
         """The partition in words (bench.py's config.partition)."""
         if self.bounds is None:
             return f"{self.world} equal x-strip(s) of {self.strip} columns"
-        return f"{self.world} x-strips of " + "/".join(str(b - a) for a, b in self.bounds) + " columns (measured-cost partition)"
+        return (f"{self.world} x-strips of " + "/".join(str(b - a) for a, b in self.bounds) + " columns"
+                + (" (measured-cost partition)" if list(self.bounds) != equal_bounds(sum(b - a for a, b in self.bounds), self.world) else "")
+                + (f", each rendered and sent in {self.chunks} column chunks" if self.chunks > 1 else ""))
