@@ -805,6 +805,21 @@ def test_heavy_tiles_on_a_tilted_horizon(oracle):
         assert_same(r.render(144, 128, 3, 40, 101), want[40:101], f"tilted horizon, heavy {heavy}, strip")
 
 
+def test_timeline_records_every_tile_once(oracle):
+    """rt_set_option("timeline", 1): the diagnostic record of when, and by which wavefront, every tile was rendered;
+    the image is unaffected."""
+    name, W, H, depth = "grid16", 160, 192, 8
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    r.set_option("help", 2)
+    r.set_option("heavy", 2)
+    r.set_option("timeline", 1)
+    assert_same(r.render(W, H, depth), want, "with the timeline on")
+    rec = r.timeline(0, W, H)
+    assert (rec[..., 0] > 0).all() and (rec[..., 1] >= rec[..., 0]).all()
+    assert 0 < int(rec[..., 3].sum()) < rec[..., 3].size             # the band's tiles, and only they, as HEAVY tiles
+
+
 def test_help_timeout_path_is_exact_and_reported(oracle):
     """rt_set_option("help_spin_limit", -1): every wait of an owner for its helpers counts as timed out.  The owner
     then tests every leaf of the scan itself (an OR: the pixels cannot change), its workgroup stops helping, and

@@ -110,6 +110,8 @@ def load_library():
     lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_render_stats.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, C.POINTER(C.c_uint64), i, vp, i]
     lib.rt_get_timing.argtypes = [vp, C.POINTER(RtTiming)]
+    lib.rt_get_timeline.argtypes = [vp, vp, i]
+    lib.rt_get_timeline.restype = i
     lib.rt_reset_timing.argtypes = [vp]
     lib.rt_get_launch_info.argtypes = [vp, C.POINTER(RtLaunchInfo)]
     lib.rt_set_option.argtypes = [vp, C.c_char_p, i]

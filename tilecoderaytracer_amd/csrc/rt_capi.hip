@@ -133,6 +133,9 @@ struct rt_scene {
     int heavy_opt = -1;           /* HEAVY tiles (the band of tile rows along the horizon line, one per workgroup, first): -1 = automatic, 0 = off, k = k - 1 rows either side */
     int help_spin_opt = RT_HELP_SPIN_LIMIT;   /* the owner's bounded wait at its desk; -1: every wait counts as timed out (tests) */
     unsigned int *h_error = nullptr;          /* pinned host word the kernels can write: a HELP wait timed out */
+    int timeline_opt = 0;                     /* diagnostic: every launch records per tile when and by whom it was rendered */
+    unsigned long long *d_timeline = nullptr;
+    size_t timeline_words = 0, timeline_valid = 0;
     int pairs_opt = 1;            /* scenes with clustered runs: the kernel that compacts (ray, leaf) pairs (0: the plain kernel) */
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int second_block_opt = 0;     /* threads per workgroup of the second pass: 0 = as the first pass, else 64..512 */
@@ -961,6 +964,20 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.heavy_half = -1;
     p.heavy_row0_q16 = p.heavy_slope_q16 = 0;
     p.help_spin_limit = s->help_spin_opt;
+    p.timeline = 0;
+    if (s->timeline_opt) {
+        const size_t words = (size_t)n_tiles * RT_TIMELINE_WORDS;
+        if (words > s->timeline_words) {
+            HIP_TRY(hipSetDevice(s->device));
+            HIP_TRY(hipDeviceSynchronize());
+            if (s->d_timeline) { HIP_TRY(hipFree(s->d_timeline)); s->d_timeline = nullptr; s->timeline_words = 0; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_timeline), words * sizeof(unsigned long long)));
+            s->timeline_words = words;
+        }
+        HIP_TRY(hipMemsetAsync(s->d_timeline, 0, words * sizeof(unsigned long long), stream));
+        s->timeline_valid = words;
+        p.timeline = (uint64_t)(uintptr_t)s->d_timeline;
+    }
     p.error_word = (uint64_t)(uintptr_t)s->h_error;
     /* automatic: only when the launch renders a strip of at most a third of the image's width -- one GPU's share on three
      * or more.  There the strip waits for its horizon tiles (4096^2, 1 024-sphere grid, longest of 8 strips: 1.39 -> 1.05 ms
@@ -1161,6 +1178,7 @@ int rt_scene_destroy(rt_scene *s) {
     if (s->d_help) (void)hipFree(s->d_help);
     if (s->d_stack) (void)hipFree(s->d_stack);
     if (s->h_error) (void)hipHostFree(s->h_error);
+    if (s->d_timeline) (void)hipFree(s->d_timeline);
     delete s;
     return RT_OK;
 }
@@ -1285,6 +1303,16 @@ int rt_get_launch_info(const rt_scene *s, rt_launch_info *out) {
     return RT_OK;
 }
 
+int rt_get_timeline(rt_scene *s, uint64_t *out, int n_words) {
+    if (!s || !out || n_words < 0) return fail(RT_ERR_INVALID, "scene/out is NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->d_timeline || s->timeline_valid == 0) return fail(RT_ERR_INVALID, "no timeline recorded: set option \"timeline\" to 1 and render");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, s->d_timeline, std::min((size_t)n_words, s->timeline_valid) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!s || !key) return fail(RT_ERR_INVALID, "scene/key is NULL");
     std::lock_guard<std::mutex> lock(s->mu);
@@ -1316,6 +1344,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         s->help_opt = value;
         return RT_OK;
     }
+    if (!std::strcmp(key, "timeline")) { s->timeline_opt = value != 0; return RT_OK; }
     if (!std::strcmp(key, "heavy")) {
         if (value < -1 || value > 4096) return fail(RT_ERR_INVALID, "heavy must be -1 (automatic), 0 (off) or 1 + the band's half-width in tile rows");
         s->heavy_opt = value;

@@ -1811,7 +1811,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
 
         }
     }
-    return defer;
+    return kMayDefer && defer;
 }
 
 template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false, bool kClusters = false, bool kRoomy = false, bool kFast = false>
@@ -2017,9 +2017,18 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             }
             wave = tile_row * p.tiles_x + tile_col;
         }
+        unsigned long long t_tile = 0ull;
+        if (p.timeline != 0ull) t_tile = __builtin_amdgcn_s_memrealtime();
         if (render_tile<kStats, kFast ? 6 : kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
             /* the tile deferred itself: the second pass renders it */
             if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
+        }
+        if (p.timeline != 0ull && lane == 0) {                   /* diagnostic: when, and by whom, this tile was rendered */
+            unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.timeline) + (size_t)wave * RT_TIMELINE_WORDS;
+            rec[0] = t_tile;
+            rec[1] = __builtin_amdgcn_s_memrealtime();
+            rec[2] = (unsigned long long)blockIdx.x * 16ull + (threadIdx.x >> 6);
+            rec[3] = head == nullptr ? 1ull : 0ull;
         }
         if (head != nullptr && !ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
     }

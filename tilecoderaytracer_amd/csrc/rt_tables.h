@@ -180,7 +180,11 @@ typedef struct RtParams {
     int32_t fast_ctl_off;                /* u32 offset (4 per quad): one control word per item */
     /* one word of host memory the kernel can write (rt_scene's sticky device error): set when a HELP wait timed out */
     uint64_t error_word;
+    /* diagnostic (option "timeline"): 0, or device memory for RT_TIMELINE_WORDS u64 per wavefront tile, row-major:
+     * {start, end (100 MHz constant clock), workgroup * 16 + wavefront, 1 if rendered as a HEAVY tile} */
+    uint64_t timeline;
 } RtParams;
+#define RT_TIMELINE_WORDS 4
 
 /* FAST tables.  Scenes without clustered sphere runs (the reference's built-in Scene: 32 objects) are walked
  * through ONE item list that serves both scans: first the objects of the shadow scan (the non-light objects of

@@ -78,6 +78,15 @@ class Renderer:
         stats = dict(zip(self.STAT_NAMES, [int(v) for v in st]))
         return (out, stats, cyc) if wave_cycles else (out, stats)
 
+    def timeline(self, x0, x1, H):
+        """Per wavefront tile of the last launch (option "timeline" = 1): array (tile rows, tile columns, 4) =
+        start, end (100 MHz clock), workgroup * 16 + wavefront, rendered-as-a-HEAVY-tile."""
+        li = self.launch_info()
+        tiles = ((H + li.tile_z - 1) // li.tile_z, (x1 - x0 + li.tile_x - 1) // li.tile_x)
+        rec = np.zeros(tiles + (4,), dtype=np.uint64)
+        capi.check(self._lib.rt_get_timeline(self._scene, rec.ctypes.data, rec.size))
+        return rec
+
     def timing(self):
         t = capi.RtTiming()
         capi.check(self._lib.rt_get_timing(self._scene, C.byref(t)))
