@@ -200,7 +200,9 @@ int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, in
                     int max_depth, float *out_rgb, uint64_t *stats, int n_stats,
                     uint64_t *wave_cycles, int n_wave_cycles);
 
-/* Diagnostic: with option "timeline" = 1 every launch records, per wavefront tile in row-major order
+/* Diagnostic BUILDS only (make -C tilecoderaytracer_amd/csrc variant NAME=timeline DEFS=-DRT_TIMELINE=1; the product
+ * library refuses the option: the few instructions it takes cost the render kernels registers): with option
+ * "timeline" = 1 every launch records, per wavefront tile in row-major order
  * (tile = tile_row * tiles_x + tile_col, rt_launch_info's tile shape), four words: {start, end on the GPU's
  * 100 MHz constant clock, workgroup * 16 + wavefront that rendered it, 1 if it was rendered as a HEAVY tile};
  * this copies up to n_words of the last launch's record (waits for the launch). */
@@ -265,7 +267,8 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   2^22 polls); -1 makes every such wait count as timed out: the owner then
  *                   tests the leaves itself (same pixels), its workgroup stops helping, and
  *                   the next rt_render / rt_get_timing returns RT_ERR_HIP once (tests)
- *   "timeline"      1 = launches record per tile when and by whom it was rendered (rt_get_timeline)
+ *   "timeline"      diagnostic builds: 1 = launches record per tile when and by whom it was rendered
+ *                   (rt_get_timeline); the product library accepts 0 only
  *   "fast"          scenes without clustered runs: 1 (default) = one kind-sorted item list
  *                   with direct test records (FAST tables), 0 = the two item tables
  *   "tight_planes"  0 = plane items get the (much larger) padding of sphere items

@@ -1,5 +1,6 @@
-"""Timeline of one launch's tiles from the PRODUCTION kernels (option "timeline"): when the queues run dry, which
-tiles finish last, how busy the wavefront slots are.  Development aid.
+"""Timeline of one launch's tiles from the production kernels' code (a diagnostic build: make -C tilecoderaytracer_amd/csrc
+variant NAME=timeline DEFS=-DRT_TIMELINE=1, then TCRT_LIBRARY=.../lib/variants/libtcrt_timeline.so): when the queues run dry,
+which tiles finish last, how busy the wavefront slots are.  Development aid.
 usage: timeline_gpu.py scene depth x0 x1 [key=value ...]"""
 import sys, os
 import numpy as np

@@ -1344,7 +1344,15 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         s->help_opt = value;
         return RT_OK;
     }
-    if (!std::strcmp(key, "timeline")) { s->timeline_opt = value != 0; return RT_OK; }
+    if (!std::strcmp(key, "timeline")) {
+#ifdef RT_TIMELINE
+        s->timeline_opt = value != 0;
+        return RT_OK;
+#else
+        return value == 0 ? (int)RT_OK
+                          : fail(RT_ERR_INVALID, "the timeline is recorded by diagnostic builds only: make -C tilecoderaytracer_amd/csrc variant NAME=timeline DEFS=-DRT_TIMELINE=1");
+#endif
+    }
     if (!std::strcmp(key, "heavy")) {
         if (value < -1 || value > 4096) return fail(RT_ERR_INVALID, "heavy must be -1 (automatic), 0 (off) or 1 + the band's half-width in tile rows");
         s->heavy_opt = value;

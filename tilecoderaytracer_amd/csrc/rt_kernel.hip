@@ -1963,7 +1963,6 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     bool fresh = true;                 /* the current queue has not been asked yet */
     for (;;) {
         int wave;                      /* tile number, row-major */
-        unsigned int *head = nullptr;
         if (kHelp && heavy_phase) {
             unsigned int *const heavy_head = tile_counter + RT_TILE_QUEUES * RT_QUEUE_STRIDE;
             int h = 0;
@@ -1987,7 +1986,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         } else {
             if (steal >= RT_TILE_QUEUES) break;
             const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
-            head = tile_counter + queue * RT_QUEUE_STRIDE;
+            unsigned int *const head = tile_counter + queue * RT_QUEUE_STRIDE;
             /* macro tiles queue, queue + 8, queue + 16, ... */
             const int queue_len = queue < n_macros ? ((n_macros - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
             if (fresh) {
@@ -2017,20 +2016,28 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             }
             wave = tile_row * p.tiles_x + tile_col;
         }
-        unsigned long long t_tile = 0ull;
-        if (p.timeline != 0ull) t_tile = __builtin_amdgcn_s_memrealtime();
+#ifdef RT_TIMELINE
+        /* diagnostic builds (make variant DEFS=-DRT_TIMELINE): when this tile was started ... (in the product kernels even these
+         * few lines cost registers: six more spilled in the plain kernel, twenty in the clustered-scene one) */
+        if (p.timeline != 0ull && lane == 0)
+            reinterpret_cast<unsigned long long *>(p.timeline)[(size_t)wave * RT_TIMELINE_WORDS] = __builtin_amdgcn_s_memrealtime();
+#endif
+        const int tile_number = here(wave);
         if (render_tile<kStats, kFast ? 6 : kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
             /* the tile deferred itself: the second pass renders it */
             if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
         }
-        if (p.timeline != 0ull && lane == 0) {                   /* diagnostic: when, and by whom, this tile was rendered */
-            unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.timeline) + (size_t)wave * RT_TIMELINE_WORDS;
-            rec[0] = t_tile;
+#ifdef RT_TIMELINE
+        if (p.timeline != 0ull && lane == 0) {                   /* ... when it was done, and by whom */
+            unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.timeline) + (size_t)tile_number * RT_TIMELINE_WORDS;
             rec[1] = __builtin_amdgcn_s_memrealtime();
             rec[2] = (unsigned long long)blockIdx.x * 16ull + (threadIdx.x >> 6);
-            rec[3] = head == nullptr ? 1ull : 0ull;
+            rec[3] = (kHelp && heavy_phase) ? 1ull : 0ull;
         }
-        if (head != nullptr && !ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
+#endif
+        /* (the queue's head is formed again here rather than kept across the tile) */
+        if (!(kHelp && heavy_phase) && !ask_ahead && lane == 0)
+            next_pop = (int)atomicAdd(tile_counter + ((my_xcc + steal) & (RT_TILE_QUEUES - 1)) * RT_QUEUE_STRIDE, 1u);
     }
     if constexpr (kHelp) {
         /* HELP: out of tiles -- serve the colleagues until they are, too */
