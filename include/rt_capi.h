@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_CAPI_VERSION 1
+#define RT_CAPI_VERSION 2      /* 2: rt_multi_*, rt_chunk_bounds, rt_get_timeline; the second pass ("defer") is gone */
 
 enum {
     RT_OK = 0,
@@ -99,7 +99,6 @@ typedef struct rt_timing {
     uint64_t launches;          /* kernel launches accumulated                                          */
     double   last_upload_ms;    /* scene-table upload in rt_scene_create                                */
     double   last_download_ms;  /* device->host copy in rt_render (0 for rt_render_device)              */
-    double   last_second_pass_ms; /* of last_kernel_ms: the second launch (deferred tiles); 0 if none */
 } rt_timing;
 
 typedef struct rt_launch_info {
@@ -108,9 +107,6 @@ typedef struct rt_launch_info {
     int32_t scene_lds_bytes;    /* of which scene tables                                        */
     int32_t grid_blocks;        /* workgroups of the last launch                                */
     int32_t tile_x, tile_z;     /* pixels per wavefront tile (tile_x * tile_z == 64)            */
-    int32_t deferred_tiles;     /* tiles the last launch left to its second pass (-1: no second pass);
-                                   reading it waits for the launch to finish                    */
-    int32_t slices;             /* wavefronts that share a deferred tile's leaves in the second pass */
     char    kernel[48];         /* name of the __global__ function the last launch ran (its first pass) */
 } rt_launch_info;
 
@@ -230,23 +226,11 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   row 0 upwards, or -- scenes with a horizon and clustered sphere
  *                   runs -- from a little above the horizon row downwards (tiles in
  *                   order of decreasing cost)
- *   "second_block"  threads per workgroup of the second pass ("defer"): 0 = as the
- *                   first pass, else a multiple of 64 up to 512
  *   "cull"          0 = the plain scans of the reference: every object one item in
  *                   Scene index order, no wavefront-level culling, no
  *                   nearest-first early exit, no sphere clustering, no
  *                   axis-aligned route (the slow baseline the fast path is
  *                   checked against, pixel for pixel, in tests/)
- *   "defer"         a tile one of whose scans is left with this many candidate
- *                   sphere-cluster leaves (1..64) by the wavefront's cull, most of
- *                   them needed by some ray, is not rendered in the first pass but
- *                   in a second one, where a whole workgroup renders it and its
- *                   wavefronts share the leaves of every scan (so that no
- *                   wavefront is kept for milliseconds by one tile);
- *                   -1 = automatic (never while "help" is on; with help off, when the
- *                   launch renders a strip of at most a sixth of the image's width),
- *                   0 = never, 65 = every tile that has a candidate leaf at all
- *                   (exercises the second pass in tests)
  *   "help"          1 (default) = scenes with clustered sphere runs: a wavefront that
  *                   has run out of tiles stays and tests candidate leaves of its
  *                   workgroup's long shadow scans (a desk in LDS, a shared cursor

@@ -11,7 +11,6 @@ for name, W, H, d, strip in cases:
     for h in (0, 1):
         r = Renderer(HostScene.named(name))
         r.set_option("help", h)
-        r.set_option("defer", 0)
         best = 1e9
         for rep in range(4 if W > 1000 else 1):
             imgs[h] = r.render(W, H, d) if strip is None else r.render(W, H, d, strip[0], strip[1])

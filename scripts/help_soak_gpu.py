@@ -13,7 +13,6 @@ for name, d in (("grid32", 4), ("grid16", 8), ("grid9", 6), ("grid32-noshadow", 
     for h in (0, 1, 2):
         rs[h] = Renderer(HostScene.named(name))
         rs[h].set_option("help", h)
-        rs[h].set_option("defer", 0)
     bufs = {h: torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0") for h in rs}
     st = torch.cuda.current_stream().cuda_stream
     for x0, x1 in [(0, S)] + [(k * S // 8, (k + 1) * S // 8) for k in range(8)] + [(3, 70), (S - 130, S - 1)]:

@@ -8,7 +8,7 @@ name, d, band, slices = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys
 lo, hi = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (480, 545)
 S = 4096
 r = Renderer(HostScene.named(name))
-r.set_option("defer", band); r.set_option("block_threads", slices)
+r.set_option("block_threads", slices)
 r.render(64, 64, d)
 _, st, cyc = r.render_stats(S, S, d, wave_cycles=True)
 dur = (cyc[..., 5].astype(np.float64) - cyc[..., 4].astype(np.float64)) / 100.0

@@ -17,7 +17,7 @@ ok = start > 0
 t0 = start[ok].min()
 start = (start - t0) / 100.0; end = (end - t0) / 100.0
 dur = end - start
-print(f"{name} d{d} columns [{x0},{x1}) {sys.argv[5:]}: deferred {r.launch_info().deferred_tiles}; span {end[ok].max():.0f} us (counting build); tiles {ok.sum()}")
+print(f"{name} d{d} columns [{x0},{x1}) {sys.argv[5:]}: span {end[ok].max():.0f} us (counting build); tiles {ok.sum()}")
 order = np.argsort(end.ravel())[::-1][:15]
 print("last finishers (row, col, start us, dur us, sphere tests):")
 for i in order:

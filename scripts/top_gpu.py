@@ -13,7 +13,7 @@ r.render(64, 64, d)
 _, st, cyc = r.render_stats(S, S, d, wave_cycles=True)
 dur = (cyc[..., 5].astype(np.float64) - cyc[..., 4].astype(np.float64)) / 100.0
 t0 = cyc[..., 4][cyc[..., 4] > 0].min()
-print(f"{name} d{d} {sys.argv[3:]}: deferred {r.launch_info().deferred_tiles}; frame span {(cyc[..., 5].max() - t0) / 100.0:.0f} us (counting build)")
+print(f"{name} d{d} {sys.argv[3:]}: frame span {(cyc[..., 5].max() - t0) / 100.0:.0f} us (counting build)")
 order = np.argsort(dur.ravel())[::-1][:25]
 for i in order:
     row, col = np.unravel_index(i, dur.shape)

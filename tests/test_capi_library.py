@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load_library()
     for name in declared_functions():
         assert getattr(lib, name) is not None, name
-    assert lib.rt_capi_version() == 1
+    assert lib.rt_capi_version() == 2
 
 
 def test_struct_sizes_match_the_header():
@@ -37,8 +37,8 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(capi.RtObjectDesc) == 4 * (4 + 3 + 3 + 3 + 2 + 3 + 12 + 2 + 1)
     assert C.sizeof(capi.RtTextureDesc) == 32
     assert C.sizeof(capi.RtCameraDesc) == 64
-    assert C.sizeof(capi.RtTiming) == 48
-    assert C.sizeof(capi.RtLaunchInfo) == 32 + 48      # + kernel[48]
+    assert C.sizeof(capi.RtTiming) == 40
+    assert C.sizeof(capi.RtLaunchInfo) == 24 + 48      # six int32 + kernel[48]
 
 
 def _create(desc):

@@ -659,52 +659,29 @@ def test_failed_option_leaves_the_handle_usable(oracle):
         assert_same(r.render(24, 24, 3), want, f"after {key}={value}")
 
 
-# ------------------------------------------------ round 2: deferred tiles (workgroup-cooperative second pass)
-@pytest.mark.parametrize("block", [64, 128, 192, 256, 512, 0])
-@pytest.mark.parametrize("name,W,H,depth", [("grid16", 96, 80, 8), ("grid9", 50, 120, 3), ("twomirrors", 24, 24, 4)])
-def test_second_pass_does_not_change_results(oracle, name, W, H, depth, block):
-    """rt_set_option("defer", 65): every tile one of whose scans has a candidate leaf goes to the
-    second pass, where a workgroup of block / 64 wavefronts renders it and the wavefronts share the
-    leaves of every scan."""
-    want = oracle.OracleScene.named(name).render(W, H, depth)
-    r = Renderer(HostScene.named(name))
-    r.set_option("defer", 65)
-    r.set_option("second_block", block)
-    r.set_option("tables", 1)                  # the second pass works from LDS tables (two mirrors: 119 KB, would default to global)
-    assert_same(r.render(W, H, depth), want, f"{name} deferred, {block // 64} wavefronts")
-    li = r.launch_info()
-    assert li.deferred_tiles > 0 and li.slices == (block or 256) // 64
-    assert_same(r.render(W, H, depth, 7, W - 5), want[7:W - 5], f"{name} deferred, {block // 64} wavefronts, strip")
-
-
-@pytest.mark.parametrize("defer,block,tile_z", [(-1, 0, 0), (0, 0, 0), (3, 128, 0), (6, 256, 4), (2, 64, 16), (5, 192, 1), (9, 0, 64), (64, 0, 0), (65, 0, 8)])
-def test_deferral_threshold_does_not_change_results(oracle, defer, block, tile_z):
+# ------------------------------------------------ shared shadow scans: HELP and HEAVY tiles on awkward scenes
+# (round 2's second launch for deferred tiles is gone: HEAVY tiles do its job inside the one launch)
+@pytest.mark.parametrize("heavy,block,tile_z", [(0, 0, 0), (1, 128, 0), (6, 256, 4), (2, 64, 16), (5, 192, 1), (9, 0, 64), (400, 0, 0), (3, 0, 8)])
+def test_shared_scans_on_a_dense_sphere_field(oracle, heavy, block, tile_z):
+    """A field of 150 overlapping spheres of very different sizes seen to the horizon: every tile shape and workgroup
+    size, help from two candidate leaves on, the HEAVY band off / one row / the whole image."""
     from scene_gen import build_sphere_field
     host = build_sphere_field(HostScene.empty(), 11, n_spheres=150)
     orc = build_sphere_field(oracle.OracleScene(), 11, n_spheres=150)
     r = Renderer(host)
-    r.set_option("defer", defer)
+    r.set_option("help", 2)
+    r.set_option("heavy", heavy)
     if block:
-        r.set_option("second_block", block)
-        r.set_option("block_threads", min(block, 256))
+        r.set_option("block_threads", block)
     if tile_z:
         r.set_option("tile_z", tile_z)
     want = orc.render(72, 333, 4)
-    assert_same(r.render(72, 333, 4), want, f"defer {defer} block {block} tile_z {tile_z}")
-    assert_same(r.render(72, 333, 4, 30, 71), want[30:71], f"defer {defer} block {block} tile_z {tile_z}, strip")
+    assert_same(r.render(72, 333, 4), want, f"heavy {heavy} block {block} tile_z {tile_z}")
+    assert_same(r.render(72, 333, 4, 30, 71), want[30:71], f"heavy {heavy} block {block} tile_z {tile_z}, strip")
 
 
-@pytest.mark.parametrize("seed", [21, 24, 27, 30])
-def test_second_pass_on_adversarial_scenes(oracle, seed):
-    host = _adversarial(HostScene.empty(), seed)
-    orc = _adversarial(oracle.OracleScene(), seed)
-    r = Renderer(host)
-    r.set_option("defer", [65, 1, 65, 2][seed % 4])
-    assert_same(r.render(96, 64, 5), orc.render(96, 64, 5), f"adversarial seed {seed}, deferred")
-
-
-def test_second_pass_inside_a_clustered_sphere_field(oracle):
-    """Negative-distance hits (ray origins inside spheres) through the shared-leaf path."""
+def test_shared_scans_inside_a_clustered_sphere_field(oracle):
+    """Negative-distance hits (ray origins inside spheres) with the shadow scans shared (HELP, HEAVY tiles)."""
     def build(scene):
         rng = np.random.RandomState(7)
         i = scene.add_sphere((3.0, 5.0, 8.0), 0.15)
@@ -721,9 +698,10 @@ def test_second_pass_inside_a_clustered_sphere_field(oracle):
         return scene
     want = build(oracle.OracleScene()).render(64, 64, 4)
     r = Renderer(build(HostScene.empty()))
-    r.set_option("defer", 65)
-    assert_same(r.render(64, 64, 4), want, "inside a clustered field, deferred")
-    assert r.launch_info().deferred_tiles > 0
+    r.set_option("help", 2)
+    for heavy in (0, 1, 100):
+        r.set_option("heavy", heavy)
+        assert_same(r.render(64, 64, 4), want, f"inside a clustered field, heavy {heavy}")
 
 
 # ------------------------------------------------ round 2: HELP (wavefronts out of tiles serve their workgroup's shadow scans)
@@ -738,7 +716,6 @@ def test_help_does_not_change_results(oracle, name, W, H, depth, block, help_lea
     r = Renderer(HostScene.named(name))
     r.set_option("help", help_leaves)
     r.set_option("block_threads", block)
-    r.set_option("defer", 0)
     for _ in range(2):                            # who helps whom depends on timing: twice
         assert_same(r.render(W, H, depth), want, f"{name} help {help_leaves}, block {block}")
     assert_same(r.render(W, H, depth, 5, W - 9), want[5:W - 9], f"{name} help {help_leaves}, block {block}, strip")
@@ -759,7 +736,6 @@ def test_help_on_and_off_render_the_same_strip_of_a_large_frame():
     for value in (1, 2, 0):
         r = Renderer(HostScene.named("grid32"))
         r.set_option("help", value)
-        r.set_option("defer", 0)
         imgs.append(r.render(4096, 4096, 4, 1536, 2048))
     assert imgs[0].shape == (512, 4096, 3)
     for img, what in ((imgs[1], "help 2"), (imgs[2], "help off")):
@@ -931,21 +907,16 @@ def test_tables_option_that_does_not_fit_is_refused(oracle):
     assert r.render(8, 8, 2).shape == (8, 8, 3)
 
 
-def test_counting_build_of_a_clustered_scene_both_passes(oracle):
-    """rt_render_stats on a scene with clustered runs: the counting variants of the first-pass and of the
-    second-pass kernel (forced deferral) must render the oracle's image too, and count the same rays."""
+def test_counting_build_of_a_clustered_scene(oracle):
+    """rt_render_stats on a scene with clustered runs: the counting variant of the clustered-scene kernel must render
+    the oracle's image too, and count the same rays as the oracle traces."""
     want = oracle.OracleScene.grid(16, True).render(96, 80, 6)
     counters = oracle.OracleScene.counters()
-    for defer in (0, 65):
-        r = Renderer(HostScene.grid(16, True))
-        r.set_option("defer", defer)
-        img, st = r.render_stats(96, 80, 6)
-        assert_same(img, want, f"counting build, defer {defer}")
-        if defer == 0:
-            assert st["nearest_rays"] == counters.nearest_rays and st["shadow_rays"] == counters.shadow_rays
-            assert st["nearest_scans_1_16"] + st["nearest_scans_17_32"] + st["nearest_scans_33_48"] + st["nearest_scans_49_64"] == st["wave_nearest_scans"]
-        else:
-            assert r.launch_info().deferred_tiles > 0
+    r = Renderer(HostScene.grid(16, True))
+    img, st = r.render_stats(96, 80, 6)
+    assert_same(img, want, "counting build")
+    assert st["nearest_rays"] == counters.nearest_rays and st["shadow_rays"] == counters.shadow_rays
+    assert st["nearest_scans_1_16"] + st["nearest_scans_17_32"] + st["nearest_scans_33_48"] + st["nearest_scans_49_64"] == st["wave_nearest_scans"]
 
 
 def test_counting_build_keeps_tables_in_lds_whenever_they_fit(oracle):

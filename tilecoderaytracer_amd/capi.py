@@ -54,7 +54,7 @@ class RtTiming(C.Structure):
     _fields_ = [
         ("last_kernel_ms", C.c_double), ("sum_kernel_ms", C.c_double),
         ("launches", C.c_uint64),
-        ("last_upload_ms", C.c_double), ("last_download_ms", C.c_double), ("last_second_pass_ms", C.c_double),
+        ("last_upload_ms", C.c_double), ("last_download_ms", C.c_double),
     ]
 
 
@@ -62,7 +62,7 @@ class RtLaunchInfo(C.Structure):
     _fields_ = [
         ("block_threads", C.c_int32), ("lds_bytes", C.c_int32), ("scene_lds_bytes", C.c_int32),
         ("grid_blocks", C.c_int32), ("tile_x", C.c_int32), ("tile_z", C.c_int32),
-        ("deferred_tiles", C.c_int32), ("slices", C.c_int32), ("kernel", C.c_char * 48),
+        ("kernel", C.c_char * 48),
     ]
 
 

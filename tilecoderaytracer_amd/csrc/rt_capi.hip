@@ -19,68 +19,21 @@
 #include "../../include/rt_capi.h"
 #include "rt_tables.h"
 
-extern "C" __global__ void rt_render_kernel(const RtParams p, const float4 *__restrict__ image,
-                                            float *__restrict__ out,
-                                            unsigned int *__restrict__ tile_counter,
-                                            float4 *__restrict__ bounce_stack,
-                                            unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_items(const RtParams p, const float4 *__restrict__ image,
-                                                  float *__restrict__ out,
-                                                  unsigned int *__restrict__ tile_counter,
-                                                  float4 *__restrict__ bounce_stack,
-                                                  unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_fast_stats(const RtParams p, const float4 *__restrict__ image,
-                                                       float *__restrict__ out,
-                                                       unsigned int *__restrict__ tile_counter,
-                                                       float4 *__restrict__ bounce_stack,
-                                                       unsigned long long *__restrict__ stats_out,
-                                                       unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_large(const RtParams p, const float4 *__restrict__ image,
-                                                  float *__restrict__ out,
-                                                  unsigned int *__restrict__ tile_counter,
-                                                  float4 *__restrict__ bounce_stack,
-                                                  unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_clusters(const RtParams p, const float4 *__restrict__ image,
-                                                     float *__restrict__ out,
-                                                     unsigned int *__restrict__ tile_counter,
-                                                     float4 *__restrict__ bounce_stack,
-                                                     unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_clusters_wide(const RtParams p, const float4 *__restrict__ image,
-                                                          float *__restrict__ out,
-                                                          unsigned int *__restrict__ tile_counter,
-                                                          float4 *__restrict__ bounce_stack,
-                                                          unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_deferring(const RtParams p, const float4 *__restrict__ image,
-                                                      float *__restrict__ out,
-                                                      unsigned int *__restrict__ tile_counter,
-                                                      float4 *__restrict__ bounce_stack,
-                                                      unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_second(const RtParams p, const float4 *__restrict__ image,
-                                                   float *__restrict__ out,
-                                                   unsigned int *__restrict__ tile_counter,
-                                                   float4 *__restrict__ bounce_stack,
-                                                   unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_second_stats(const RtParams p, const float4 *__restrict__ image,
-                                                         float *__restrict__ out,
-                                                         unsigned int *__restrict__ tile_counter,
-                                                         float4 *__restrict__ bounce_stack,
-                                                         unsigned long long *__restrict__ stats_out,
-                                                         unsigned int *__restrict__ defer_list);
-
-extern "C" __global__ void rt_render_kernel_stats(const RtParams p, const float4 *__restrict__ image,
-                                                  float *__restrict__ out,
-                                                  unsigned int *__restrict__ tile_counter,
-                                                  float4 *__restrict__ bounce_stack,
-                                                  unsigned long long *__restrict__ stats_out,
-                                                  unsigned int *__restrict__ defer_list);
+#define RT_DECLARE_KERNEL(name)                                                                                   \
+    extern "C" __global__ void name(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out, \
+                                    unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,  \
+                                    unsigned int *__restrict__ help_area)
+#define RT_DECLARE_STATS_KERNEL(name)                                                                             \
+    extern "C" __global__ void name(const RtParams p, const float4 *__restrict__ image, float *__restrict__ out, \
+                                    unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,  \
+                                    unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ help_area)
+RT_DECLARE_KERNEL(rt_render_kernel);                  /* FAST tables (scenes without clustered runs) */
+RT_DECLARE_KERNEL(rt_render_kernel_items);            /* the two item tables, no clustered runs      */
+RT_DECLARE_KERNEL(rt_render_kernel_large);            /* tables in global memory                     */
+RT_DECLARE_KERNEL(rt_render_kernel_clusters);         /* clustered sphere runs, six wavefronts per SIMD */
+RT_DECLARE_KERNEL(rt_render_kernel_clusters_wide);    /* ... five */
+RT_DECLARE_STATS_KERNEL(rt_render_kernel_stats);      /* the counting builds */
+RT_DECLARE_STATS_KERNEL(rt_render_kernel_fast_stats);
 
 namespace {
 
@@ -103,9 +56,9 @@ struct Quad { float v[4]; };
 
 float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
-struct EventPair { hipEvent_t start, mid, stop; bool pending, two_passes; };
+struct EventPair { hipEvent_t start, stop; bool pending; };
 constexpr int kEventRing = 64;
-constexpr int kCounterWords = (RT_TILE_QUEUES + 1) * RT_QUEUE_STRIDE;   /* 8 queue heads + the second pass's, own cache lines */
+constexpr int kCounterWords = (RT_TILE_QUEUES + 1) * RT_QUEUE_STRIDE;   /* 8 queue heads + the HEAVY tiles', own cache lines */
 
 } // namespace
 
@@ -138,10 +91,6 @@ struct rt_scene {
     size_t timeline_words = 0, timeline_valid = 0;
     int pairs_opt = 1;            /* scenes with clustered runs: the kernel that compacts (ray, leaf) pairs (0: the plain kernel) */
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
-    int second_block_opt = 0;     /* threads per workgroup of the second pass: 0 = as the first pass, else 64..512 */
-    int defer_opt = -1;           /* a scan with this many candidate leaves (most of them needed by some ray) defers its tile
-                                     to the second, workgroup-cooperative pass; -1 = automatic (RT_DEFER_LEAVES when the
-                                     scene has clustered runs), 0 = never */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int leaf_items_opt = 1;       /* clustered runs appear in the item tables leaf by leaf (0: group by group) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
@@ -153,9 +102,6 @@ struct rt_scene {
     int n_clusters = 0;
     /* tile queue heads, one per in-flight launch (same ring as the events) */
     unsigned int *d_counters = nullptr;
-    /* defer list {count, tile, tile, ...} of the launch in flight (launches of one handle are stream-ordered) */
-    unsigned int *d_defer = nullptr;
-    size_t d_defer_words = 0;
     /* HELP: 2 KB per workgroup for the rays a wavefront publishes at its workgroup's desk */
     void *d_help = nullptr;
     size_t d_help_bytes = 0;
@@ -714,9 +660,7 @@ int ensure_events(rt_scene *s) {
     for (int i = 0; i < kEventRing; ++i) {
         HIP_TRY(hipEventCreate(&s->ev[i].start));
         HIP_TRY(hipEventCreate(&s->ev[i].stop));
-        HIP_TRY(hipEventCreate(&s->ev[i].mid));
         s->ev[i].pending = false;
-        s->ev[i].two_passes = false;
     }
     s->ev_ready = true;
     return RT_OK;
@@ -729,12 +673,6 @@ int drain_event(rt_scene *s, int i) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e.start, e.stop));
     s->timing.last_kernel_ms = ms;
-    s->timing.last_second_pass_ms = 0.0;
-    if (e.two_passes) {
-        float ms2 = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms2, e.mid, e.stop));
-        s->timing.last_second_pass_ms = ms2;
-    }
     s->timing.sum_kernel_ms += ms;
     s->timing.launches += 1;
     e.pending = false;
@@ -896,28 +834,6 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         p.first_macro_row = (int)std::min(macro_rows - 1, macro_rows * (long long)permille / 1000);
         if (p.first_macro_row < 0) p.first_macro_row = 0;
     }
-    /* deferred tiles (rt_tables.h): only scenes with clustered sphere runs have leaves to count */
-    p.defer_leaves = 0;
-    p.coop_off = 0;
-    if (s->n_clusters > 0 && s->cull_opt && !global_tables)
-        /* automatic: never while HELP is on (option "help", the default: wavefronts out of tiles serve their
-         * workgroup's long shadow scans inside the one launch; measured on N=8 strips of 4096^2, longest strip:
-         * 1 024-sphere grid 2.66 ms plain, 1.86 ms deferring, 1.78 ms helping; 256-sphere grid d8 1.60 / 1.58 /
-         * 1.23 ms).  With help off: only when the launch renders a NARROW strip of the image (a sixth of its
-         * width or less: one GPU's share of a frame on six or more GPUs): there the strip cannot finish before
-         * its longest tile, and the second pass cuts that tile to a quarter; on a whole frame, or a half or a
-         * quarter of one, the heavy tiles are simply handed out first and the second pass only costs its
-         * overhead (whole frame +13 %, half frame 2.9 -> 4.3 ms, quarter 2.5 -> 2.9 ms, eighth 2.4 -> 1.9 ms) */
-        p.defer_leaves = s->defer_opt == 65 ? -1
-                       : s->defer_opt >= 0 ? s->defer_opt
-                       : (!s->help_opt && (long long)(x1 - x0) * 6 <= (long long)W ? RT_DEFER_LEAVES : 0);
-    /* the second pass's workgroups: more wavefronts per tile (option "second_block", default: as many as the first pass);
-     * only the leader keeps a bounce stack; the cooperation area sits behind tables and stack */
-    const int block2 = s->second_block_opt ? s->second_block_opt : block;
-    const int stack_lds_levels2 = stack_lds_levels;              /* same levels in LDS, for 64 threads only */
-    const int coop_off = p.stack_off + stack_lds_levels2 * 64;
-    const size_t lds_bytes2 = ((size_t)coop_off + RT_COOP_QUADS(block2 / 64)) * 16;
-    if (lds_bytes2 > RT_MAX_LDS_BYTES) p.defer_leaves = 0;      /* no room for the second pass's LDS area */
     p.n_tiles = (int)n_tiles;
     const int waves_per_block = block / 64;
     const long long blocks_all = (n_tiles + waves_per_block - 1) / waves_per_block;
@@ -943,10 +859,10 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    /* first-pass kernel: the plain one, the one for clustered scenes (in the register budget that fits the
-     * occupancy LDS allows), the large-scene one, or the one whose tiles may defer themselves */
+    /* the kernel: FAST tables, item tables, the one for clustered scenes (in the register budget that fits the
+     * occupancy LDS allows), or the large-scene one */
     /* HELP (rt_kernel.hip): the clustered-scene kernels keep a desk of a few LDS words behind tables and stack */
-    const bool clusters_kernel = !d_stats && !global_tables && p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt;
+    const bool clusters_kernel = !d_stats && !global_tables && s->n_clusters > 0 && s->pairs_opt;
     p.desk_off = 0;
     p.help_rays_quads = 0;
     p.help_leaves = s->help_opt >= 2 ? s->help_opt : RT_HELP_LEAVES;
@@ -1011,7 +927,6 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
 #define RT_KERNEL(k) Kernel{(const void *)k, #k}
     const Kernel first_kernel = d_stats ? (fast_tables ? RT_KERNEL(rt_render_kernel_fast_stats) : RT_KERNEL(rt_render_kernel_stats))
                                 : global_tables ? RT_KERNEL(rt_render_kernel_large)
-                                : p.defer_leaves != 0 ? RT_KERNEL(rt_render_kernel_deferring)
                                 : (s->n_clusters > 0 && s->pairs_opt)
                                       ? (clusters_wide ? RT_KERNEL(rt_render_kernel_clusters_wide) : RT_KERNEL(rt_render_kernel_clusters))
                                 : fast_tables ? RT_KERNEL(rt_render_kernel)
@@ -1068,50 +983,14 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     s->ev_next = (s->ev_next + 1) % kEventRing;
     unsigned int *counter = s->d_counters + (size_t)slot * kCounterWords;
     HIP_TRY(hipMemsetAsync(counter, 0, (size_t)kCounterWords * sizeof(unsigned int), stream));
-    if (p.defer_leaves != 0) {
-        const size_t words = 1 + (size_t)n_tiles;
-        if (words > s->d_defer_words) {
-            HIP_TRY(hipDeviceSynchronize());
-            if (s->d_defer) { HIP_TRY(hipFree(s->d_defer)); s->d_defer = nullptr; s->d_defer_words = 0; }
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_defer), words * sizeof(unsigned int)));
-            s->d_defer_words = words;
-        }
-        HIP_TRY(hipMemsetAsync(s->d_defer, 0, sizeof(unsigned int), stream));      /* the count */
-    }
     HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
-    /* first pass: every tile; second pass (only if tiles can defer themselves): the deferred ones, one per workgroup.
-     * Same stream: the second launch starts when the first has drained and sees its list. */
-    s->ev[slot].two_passes = p.defer_leaves != 0;
-    s->launch.deferred_tiles = p.defer_leaves != 0 ? 0 : -1;
-    s->launch.slices = block2 / 64;
     const float4 *image_arg = reinterpret_cast<const float4 *>(s->d_image);
     float4 *stack_arg = reinterpret_cast<float4 *>(s->d_stack);
-    /* the clustered-scene kernels get the workgroups' HELP areas where the others get the defer list */
-    unsigned int *list_arg = (p.defer_leaves == 0 && s->n_clusters > 0 && s->pairs_opt && !d_stats && !global_tables)
-                                 ? reinterpret_cast<unsigned int *>(s->d_help) : s->d_defer;
+    unsigned int *list_arg = reinterpret_cast<unsigned int *>(s->d_help);      /* the clustered-scene kernels' HELP areas (unused by the others) */
     {
         void *args6[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &list_arg};
         void *args7[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &d_stats, &list_arg};
         HIP_TRY(hipLaunchKernel(first, dim3((unsigned)blocks), dim3((unsigned)block), d_stats ? args7 : args6, (size_t)lds_bytes, stream));
-    }
-    if (p.defer_leaves != 0) {
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s->ev[slot].mid, stream));
-        p.coop_off = coop_off;
-        p.stack_lds_levels = stack_lds_levels2;
-        p.stack_stride = 64;
-        int per_cu2 = 0;
-        const void *second = d_stats ? (const void *)rt_render_kernel_second_stats : (const void *)rt_render_kernel_second;
-        HIP_TRY(hipFuncSetAttribute(second, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes2));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, second, block2, lds_bytes2));
-        if (per_cu2 < 1) per_cu2 = 1;
-        /* never more workgroups than the first pass: the bounce stack has one slice per workgroup */
-        const long long blocks2 = std::min(blocks, (long long)per_cu2 * (long long)s->n_cus);
-        {
-            void *args6[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &s->d_defer};
-            void *args7[] = {&p, &image_arg, &d_out, &counter, &stack_arg, &d_stats, &s->d_defer};
-            HIP_TRY(hipLaunchKernel(second, dim3((unsigned)blocks2), dim3((unsigned)block2), d_stats ? args7 : args6, lds_bytes2, stream));
-        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
@@ -1170,11 +1049,10 @@ int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     if (s->d_image || s->d_fb || s->d_counters || s->ev_ready) (void)hipSetDevice(s->device);
     if (s->ev_ready)
-        for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].mid); (void)hipEventDestroy(s->ev[i].stop); }
+        for (int i = 0; i < kEventRing; ++i) { (void)hipEventDestroy(s->ev[i].start); (void)hipEventDestroy(s->ev[i].stop); }
     if (s->d_image) (void)hipFree(s->d_image);
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_counters) (void)hipFree(s->d_counters);
-    if (s->d_defer) (void)hipFree(s->d_defer);
     if (s->d_help) (void)hipFree(s->d_help);
     if (s->d_stack) (void)hipFree(s->d_stack);
     if (s->h_error) (void)hipHostFree(s->h_error);
@@ -1293,13 +1171,6 @@ int rt_reset_timing(rt_scene *s) {
 int rt_get_launch_info(const rt_scene *s, rt_launch_info *out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "scene/out is NULL");
     *out = s->launch;
-    if (s->launch.deferred_tiles >= 0 && s->d_defer) {
-        unsigned int n = 0;
-        HIP_TRY(hipSetDevice(s->device));
-        if (s->has_last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
-        HIP_TRY(hipMemcpy(&n, s->d_defer, sizeof(n), hipMemcpyDeviceToHost));
-        out->deferred_tiles = (int32_t)n;
-    }
     return RT_OK;
 }
 
@@ -1368,17 +1239,6 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
 
-    if (!std::strcmp(key, "second_block")) {
-        if (value != 0 && (value < 64 || value > 512 || (value % 64) != 0))
-            return fail(RT_ERR_INVALID, "second_block must be 0 (auto) or a multiple of 64 up to 512");
-        s->second_block_opt = value;
-        return RT_OK;
-    }
-    if (!std::strcmp(key, "defer")) {
-        if (value < -1 || value > 65) return fail(RT_ERR_INVALID, "defer is a number of candidate leaves in [1, 64], 0 (never), -1 (automatic) or 65 (every tile with a candidate leaf)");
-        s->defer_opt = value;
-        return RT_OK;
-    }
     if (!std::strcmp(key, "grid_mult")) {
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "grid_mult must be in [0, 64]");
         s->grid_mult = value;

@@ -25,10 +25,10 @@
  *    against a bound of all 64 rays, one ballot yields the candidates.
  *  - Scenes with clustered sphere runs: the (ray, leaf) pairs that the per-lane
  *    box tests leave are compacted into full wavefront rounds (PAIRS, NEAREST
- *    PAIRS); tiles with scans that keep one wavefront busy for milliseconds can
- *    defer themselves to a second launch in which a whole workgroup shares the
- *    leaves of every scan (DEFERRED tiles).  The same tests on the same
- *    operands; nearest = minimum of (distance, Scene index), shadow = OR.
+ *    PAIRS); long shadow scans are shared with the workgroup's wavefronts that have
+ *    nothing else to do (HELP), and the tiles known to be long are rendered one per
+ *    workgroup from the start (HEAVY tiles).  The same tests on the same operands;
+ *    nearest = minimum of (distance, Scene index), shadow = OR.
  *  - One body, several __global__ entry points (bottom of the file); the host
  *    picks by scene (rt_capi.hip, launch()).
  *
@@ -496,29 +496,7 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
     *upper_a = uniform_f(max_positive ? nan : -rmax);
 }
 
-/* DEFERRED tiles (rt_tables.h).  A first-pass tile (kMode 2) may defer itself: when the
- * bundle cull of one of its scans leaves p.defer_leaves or more candidate leaves of
- * clustered sphere runs AND some ray of a sample really needs most of the leaves it is
- * asked about -- horizon rows, rays reflected to grazing directions: such a ray tests
- * most of the scene, which keeps ONE wavefront busy for hundreds of microseconds per
- * scan -- the scan sets *defer and the tile is abandoned before the expensive scan runs.
- * The second pass renders the deferred tiles with whole workgroups (kMode 3): wavefront
- * 0, the LEADER, renders the tile exactly like a first-pass tile, except that it deals
- * the candidate leaves of a scan to all wavefronts of the workgroup -- it publishes its
- * 64 rays and the candidate mask in LDS; wavefront w tests candidates w, w + n, w + 2n, ...
- * for all 64 rays -- and combines the shares afterwards: the nearest hit is the minimum
- * of (distance, Scene index) over the shares, the shadow verdict their OR.  Both are
- * independent of the order of the tests, hence exactly what the reference's in-order
- * scans find (src/RayTracer.cpp:71-80, 727-729).  Same instructions as one wavefront
- * would issue, on as many SIMDs as the workgroup has wavefronts. */
-#define RT_COOP_RAY0 0           /* 64 quads: ray origin, bound (nearest so far / distance to the light)   */
-#define RT_COOP_RAY1 64          /* 64 quads: ray direction, bits (nearest: Scene index so far; shadow: 1) or RT_COOP_IDLE */
-#define RT_COOP_CMD 128          /* 1 quad: bits {scan: 0 exit / 1 nearest / 2 shadow, first item of the round, mask lo, mask hi} */
-#define RT_COOP_PART 129         /* 32 quads per wavefront: its 64 lanes' {distance, Scene index} (nearest) or its ballot (shadow) */
-#define RT_COOP_IDLE 0x80000000u
-#ifndef RT_COOP_MIN_LEAVES
-#define RT_COOP_MIN_LEAVES 8     /* fewer candidate leaves than this: the leader tests them itself */
-#endif
+#define RT_COOP_IDLE 0x80000000u     /* state word of a published ray whose lane has no shadow ray (or is blocked already) */
 
 /* HELP (clustered scenes, whole frames and wide strips: rt_render_kernel_clusters*).  A wavefront that has run
  * out of tiles does not leave: it waits at its workgroup's DESK (ten words of LDS) until all the workgroup's
@@ -544,48 +522,9 @@ __device__ __forceinline__ void desk_write(uint32_t *desk, const int word, const
     __hip_atomic_store(desk + word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-/* A share of the candidate leaves of one round of a nearest-hit scan: candidates number
- * share, share + n_shares, ... of leaf_mask (bit i = item base + i), tested for this
- * wavefront's 64 rays; the code of the RT_KIND_SPHERE_LEAF case of nearest_hit_items(). */
-template <bool kStats>
-__device__ __forceinline__ void near_leaf_share(const float4 *lds, const float4 *items, const int base,
-                                                unsigned long long leaf_mask, const int share, const int n_shares,
-                                                const bool active, const V3 o, const V3 d, const V3 inv,
-                                                float *best_io, int *best_idx_io, Stats<kStats> &st) {
-    const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
-    float best = *best_io;
-    int best_idx = *best_idx_io;
-    int turn = 0;
-    while (leaf_mask != 0ull) {
-        const int item = base + (__ffsll((long long)leaf_mask) - 1);
-        leaf_mask &= leaf_mask - 1ull;
-        const bool mine = turn == share;
-        turn = turn + 1 == n_shares ? 0 : turn + 1;
-        if (!mine) continue;
-        const float4 i0 = items[2 * item], i1 = items[2 * item + 1];
-        const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
-        const int n = (int)((bits >> 8) & 255u);
-        const float4 *g = lds + (bits >> 16);
-        const uint32_t *ids = lds_u32 + bits1;
-        st_wave(st, ST_WAVE_BOX_TESTS);
-        const bool lane_needs = active && box_needed(i0, i1, o, inv, best);
-        if (!wave_any(lane_needs)) continue;
-#pragma unroll 2
-        for (int i = 0; i < n; ++i) {
-            bool hit; float t;
-            st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
-            sphere_distance(g[i], o, d, &hit, &t);
-            if (wave_any(hit)) {
-                const int member = (int)ids[i];
-                if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
-            }
-        }
-    }
-    *best_io = best;
-    *best_idx_io = best_idx;
-}
+/* A share of the candidate leaves of one round of a shadow scan (HELP): candidates number share, share + n_shares, ...
+ * of leaf_mask (bit i = item base + i), tested for this wavefront's 64 rays; returns blocked */
 
-/* the same for a shadow scan: returns blocked */
 template <bool kStats>
 __device__ __forceinline__ bool shadow_leaf_share(const float4 *lds, const float4 *items, const int base,
                                                   unsigned long long leaf_mask, const int share, const int n_shares,
@@ -677,27 +616,6 @@ __device__ __forceinline__ void serve_desk(const RtParams &p, const float4 *lds,
     if (lane == 0) atomicSub(desk + RT_DESK_INSIDE, 1u);
 }
 
-/* First-pass tiles: does some ray of the wavefront need most of the candidate leaves of
- * this round?  Every lane asks about four of them (lane, lane + 16, ... : four box tests
- * for the wavefront); a ray that needs three out of four of the candidates it asked
- * about makes the scan -- and with it the tile -- one for the second pass. */
-__device__ __forceinline__ bool some_ray_needs_most_leaves(const float4 *items, const int base, const int n_items,
-                                                           const unsigned long long leaf_mask, const bool active,
-                                                           const V3 o, const V3 inv, const float bound) {
-    const int lane = (int)(threadIdx.x & 63u);
-    int asked = 0, needed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int bit = (lane + 16 * j) & 63;
-        const bool candidate = active && ((leaf_mask >> bit) & 1ull) != 0ull;
-        const int probe = min(base + bit, n_items - 1);
-        const bool need = candidate && box_needed(items[2 * probe], items[2 * probe + 1], o, inv, bound);
-        asked += candidate ? 1 : 0;
-        needed += need ? 1 : 0;
-    }
-    return wave_any(asked >= 2 && 4 * needed >= 3 * asked);
-}
-
 /* NEAREST PAIRS -- the pair compaction of the shadow scans (PAIRS, above in_shade()) for the nearest-hit
  * scan.  A leaf that fewer than RT_PAIR_DIRECT_LANES lanes need is not tested for the whole wavefront:
  * the needing lanes push their lane number to the next free slots, the slots note the leaf, and a
@@ -776,15 +694,14 @@ __device__ __forceinline__ void flush_near_pairs(const float4 *lds, NearPairs &p
     pb.pushes = 0;
 }
 
-/* kMode: 0 a first-pass tile of a scene without clustered runs; 4 of a scene with them (PAIRS below), 5 the same in the
- * kernel with the larger register budget; 2 one that may also defer itself; 3 the leader of a second-pass workgroup */
+/* kMode: 0 a tile of a scene without clustered runs (item tables); 4 of a scene with them (PAIRS, HELP), 5 the same in the
+ * kernel with the larger register budget; 6 FAST tables (nearest_hit_fast / in_shade_fast) */
 template <bool kStats, int kMode>
 __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float4 *lds, float4 *wlds, const bool active,
                                                   const V3 o, const V3 d, const bool have_origin_box,
                                                   const V3 origins_lo, const V3 origins_hi,
-                                                  float *best_out, int *best_idx_out, Stats<kStats> &st,
-                                                  bool *defer) {
-    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3, kPairs = kMode != 0;
+                                                  float *best_out, int *best_idx_out, Stats<kStats> &st) {
+    constexpr bool kPairs = kMode != 0;
     NearPairs pairs = {0, 0, 0, 0, 0, 0};
     float best = 65535.0f;
     int best_idx = -1;
@@ -859,38 +776,6 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
          * would otherwise test all of it.  The order of the tests does not change the
          * result: the winner is the minimum of (distance, Scene index), which is what
          * the reference's in-order scan with a strict `<` finds. */
-        /* which candidates are leaves of clustered runs: the items from p.near_first_leaf on */
-        if ((kLeader || kMayDefer) && p.n_clusters > 0) {
-            const int plain = min(max(p.near_first_leaf - base, 0), 64);
-            const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
-            if constexpr (kMayDefer) {
-                if (p.defer_leaves < 0 ? leaf_mask != 0ull      /* < 0: every tile with a candidate leaf (tests) */
-                                       : (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves &&
-                                          some_ray_needs_most_leaves(items, base, p.n_near_items, leaf_mask, active, o, inv, best))) {
-                    *defer = true; mask = 0ull; base = p.n_near_items;      /* ends the scan */
-                }
-            } else if (__popcll(leaf_mask) >= RT_COOP_MIN_LEAVES) {
-                /* the workgroup shares these leaves (DEFERRED tiles above) */
-                mask &= ~leaf_mask;
-                if (lane >= plain) key = 0xFFFFFFFFu;               /* not the ordered loop's business */
-                float4 *coop = wlds + p.coop_off;
-                const int n_shares = (int)(blockDim.x >> 6);
-                coop[RT_COOP_RAY0 + lane] = make_float4(o.x, o.y, o.z, best);
-                coop[RT_COOP_RAY1 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(active ? (uint32_t)best_idx : RT_COOP_IDLE));
-                if (lane == 0)
-                    coop[RT_COOP_CMD] = make_float4(__uint_as_float(1u), __uint_as_float((uint32_t)base),
-                                                    __uint_as_float((uint32_t)leaf_mask), __uint_as_float((uint32_t)(leaf_mask >> 32)));
-                __syncthreads();
-                near_leaf_share<kStats>(lds, items, base, leaf_mask, 0, n_shares, active, o, d, inv, &best, &best_idx, st);
-                __syncthreads();
-                const float2 *part = reinterpret_cast<const float2 *>(coop + RT_COOP_PART);
-                for (int w = 1; w < n_shares; ++w) {
-                    const float2 other = part[w * 64 + lane];
-                    const int oi = __float_as_int(other.y);
-                    if (oi >= 0 && (best_idx < 0 || nearer(other.x, oi, best, best_idx))) { best = other.x; best_idx = oi; }
-                }
-            }
-        }
         const bool ordered = cull && __popcll(mask) >= RT_ORDER_MIN_CANDIDATES;
         while (mask != 0ull) {
             int src;
@@ -1096,11 +981,10 @@ __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPair
 template <bool kStats, int kMode>
 __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
-                                         const V3 origins_centre, const V3 origins_half, Stats<kStats> &st,
-                                         bool *defer) {
-    constexpr bool kMayDefer = kMode == 2, kLeader = kMode == 3, kPairs = kMode != 0;
+                                         const V3 origins_centre, const V3 origins_half, Stats<kStats> &st) {
+    constexpr bool kPairs = kMode != 0;
     constexpr bool kHelped = kMode == 4 || kMode == 5;      /* a first-pass tile of a clustered scene: HELP */
-    constexpr bool kRoomy = kMode == 5 || kMode == 3;       /* kernels with registers to spare: the pair flush tests four members abreast */
+    constexpr bool kRoomy = kMode == 5;                     /* the kernel with registers to spare: the pair flush tests four members abreast */
     ShadowPairs pairs = {0, 0};
     bool blocked = !active;
     int stat_my_leaves = 0;
@@ -1154,7 +1038,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         }
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
-        if ((kLeader || kMayDefer || kHelped) && p.n_clusters > 0) {
+        if (kHelped && p.n_clusters > 0) {
             const int plain = min(max(p.shadow_first_leaf - base, 0), 64);
             const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
             if constexpr (kHelped) {                                 /* HELP, above near_leaf_share() */
@@ -1208,31 +1092,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                         }
                         mask &= ~leaf_mask;
                     }
-                }
-            }
-            if constexpr (kMayDefer) {
-                if (p.defer_leaves < 0 ? leaf_mask != 0ull
-                                       : (p.defer_leaves > 0 && __popcll(leaf_mask) >= p.defer_leaves &&
-                                          some_ray_needs_most_leaves(items, base, p.n_shadow_items, leaf_mask, !blocked, o, inv, dist_to_light))) {
-                    *defer = true; mask = 0ull; base = p.n_shadow_items;    /* ends the scan */
-                }
-            } else if (kLeader && __popcll(leaf_mask) >= RT_COOP_MIN_LEAVES) {
-                /* the workgroup shares these leaves (DEFERRED tiles, above nearest_hit_items()) */
-                mask &= ~leaf_mask;
-                float4 *coop = wlds + p.coop_off;
-                const int n_shares = (int)(blockDim.x >> 6);
-                coop[RT_COOP_RAY0 + lane] = make_float4(o.x, o.y, o.z, dist_to_light);
-                coop[RT_COOP_RAY1 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(blocked ? RT_COOP_IDLE : 1u));
-                if (lane == 0)
-                    coop[RT_COOP_CMD] = make_float4(__uint_as_float(2u), __uint_as_float((uint32_t)base),
-                                                    __uint_as_float((uint32_t)leaf_mask), __uint_as_float((uint32_t)(leaf_mask >> 32)));
-                __syncthreads();
-                blocked = shadow_leaf_share<kStats>(lds, items, base, leaf_mask, 0, n_shares, blocked, o, d, inv, dist_to_light, st);
-                __syncthreads();
-                const uint32_t *part = reinterpret_cast<const uint32_t *>(coop + RT_COOP_PART);
-                for (int w = 1; w < n_shares; ++w) {
-                    const unsigned long long theirs = (unsigned long long)part[w * 128] | ((unsigned long long)part[w * 128 + 1] << 32);
-                    blocked = blocked || ((theirs >> lane) & 1ull) != 0ull;
                 }
             }
         }
@@ -1555,20 +1414,17 @@ __device__ __forceinline__ size_t hbm_stack_entry(const RtParams &p, const int l
     return (size_t)(row * (unsigned int)here(p.stack_stride) + threadIdx.x);
 }
 
-/* One wavefront tile: camera rays, the bounce loop, the unwind, the store.  Returns true
- * if the tile deferred itself (kMode 2; nothing is stored then). */
+/* One wavefront tile: camera rays, the bounce loop, the unwind, the store. */
 template <bool kStats, int kMode>
-__device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays,
+__device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays,
                                             const uint32_t *__restrict__ ctl_words, float *__restrict__ out,
                                             float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
                                             Stats<kStats> &st, const int wave, const int my_xcc, const int steal) {
-    constexpr bool kMayDefer = kMode == 2;
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
     const int lane = (int)(threadIdx.x & 63u);
     unsigned long long t_start = 0ull, t_start_real = 0ull;
     const int tile_row = wave / p.tiles_x;                  /* tile number, row-major */
     const int tile_col = wave - tile_row * p.tiles_x;
-    bool defer = false;
     unsigned int tile_sphere0 = 0u, tile_box0 = 0u;
     if constexpr (kStats) {
         tile_sphere0 = st.c[ST_WAVE_SPHERE_TESTS]; tile_box0 = st.c[ST_WAVE_BOX_TESTS];
@@ -1622,8 +1478,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
             st_wave(st, n_alive <= 16 ? ST_NEAREST_1_16 : n_alive <= 32 ? ST_NEAREST_17_32 : n_alive <= 48 ? ST_NEAREST_33_48 : ST_NEAREST_49_64);
         }
         if constexpr (kMode == 6) nearest_hit_fast<kStats>(p, lds, ctl_words, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);
-        else nearest_hit_items<kStats, kMode>(p, lds, wlds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st, &defer);   /* whole wavefront, converged */
-        if (kMayDefer && defer) alive = false;                /* deferred: nothing more to trace, nothing to store */
+        else nearest_hit_items<kStats, kMode>(p, lds, wlds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);   /* whole wavefront, converged */
         st_cycles(st, ST_CYCLES_NEAREST, t_scan);
         const unsigned long long t_winner = st_clock<kStats>();
         if (alive) {
@@ -1700,8 +1555,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
                 const unsigned long long t_shadow = st_clock<kStats>();
                 bool blocked;
                 if constexpr (kMode == 6) blocked = in_shade_fast<kStats>(p, lds, ctl_words, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
-                else blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st, &defer);
-                if (kMayDefer && defer) { shade = false; alive = false; }
+                else blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
                     /* the winner's material, re-read here rather than kept in registers across the shadow scan */
@@ -1785,9 +1639,7 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
         }
     }
 
-    bool stores = inside;
-    if constexpr (kMayDefer) stores = inside && !defer;
-    if (stores) {
+    if (inside) {
         const int tzl_b = here(p.tile_z_log2);
         const int sx = here(tile_col) * (64 >> tzl_b) + (lane >> tzl_b);   /* x - x0 */
         const int sz = (here(tile_row) << tzl_b) + (lane & ((1 << tzl_b) - 1));
@@ -1811,17 +1663,15 @@ __device__ __forceinline__ bool render_tile(const RtParams &p, const float4 *lds
 
         }
     }
-    return kMayDefer && defer;
 }
 
-template <bool kStats, bool kSecondPass, bool kMayDefer, bool kGlobalTables = false, bool kClusters = false, bool kRoomy = false, bool kFast = false>
+template <bool kStats, bool kGlobalTables = false, bool kClusters = false, bool kRoomy = false, bool kFast = false>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
                                             float4 *__restrict__ bounce_stack,
                                             unsigned long long *__restrict__ stats_out,
-                                            unsigned int *__restrict__ defer_list) {
-    extern __shared__ float4 wlds[];                          /* LDS: the tables, the low levels of the bounce stack, the second pass's area */
-    if (kSecondPass && defer_list[0] == 0u) return;          /* nothing was deferred */
+                                            unsigned int *__restrict__ help_area) {
+    extern __shared__ float4 wlds[];                          /* LDS: the tables, the low levels of the bounce stack, the HELP desk */
     Stats<kStats> st;
     if constexpr (kStats) {
 #pragma unroll
@@ -1836,9 +1686,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const float4 *lds = kGlobalTables ? image : wlds;
     /* FAST tables: the items' control words are read from the image in global memory (scalar loads) */
     const uint32_t *__restrict__ ctl_words = reinterpret_cast<const uint32_t *>(image) + (kFast ? p.fast_ctl_off : 0);
-    /* HELP: the clustered-scene kernels get the workgroups' ray areas where the others get the defer list */
-    constexpr bool kHelp = kClusters && !kMayDefer && !kSecondPass;
-    float4 *help_rays = kHelp ? reinterpret_cast<float4 *>(defer_list) : nullptr;
+    /* HELP: the clustered-scene kernels get the workgroups' ray areas (128 quads each) */
+    constexpr bool kHelp = kClusters;
+    float4 *help_rays = kHelp ? reinterpret_cast<float4 *>(help_area) : nullptr;
     if constexpr (kHelp) {
         if (p.help_rays_quads != 0 && threadIdx.x < RT_DESK_WORDS) reinterpret_cast<uint32_t *>(wlds + p.desk_off)[threadIdx.x] = 0u;
     }
@@ -1872,62 +1722,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * speed matter only; any XCC_ID value gives the same image).  All lanes are
      * active here and every wavefront walks all 8 queues to their end, so the
      * grid always drains.
-     *
-     * Two passes (rt_tables.h, "deferred tiles"): pass 0 as above; a tile that defers
-     * itself is appended to defer_list.  Pass 1 -- a second launch, after the first has
-     * drained -- deals the listed tiles' sub-tiles from one counter. */
+     */
     const int lane = (int)(threadIdx.x & 63u);
     const int my_xcc = (int)(__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u);
-  if constexpr (kSecondPass) {
-    /* second pass: the workgroup renders one deferred tile at a time (DEFERRED tiles, above) */
-    float4 *coop = wlds + p.coop_off;
-    const int my_wave = (int)(threadIdx.x >> 6), n_waves = (int)(blockDim.x >> 6);
-    if (my_wave == 0) {
-        const int n_deferred = (int)defer_list[0];
-        unsigned int *const head = tile_counter + RT_TILE_QUEUES * RT_QUEUE_STRIDE;
-        int next_pop = 0;
-        if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-        for (;;) {
-            const int pop = __builtin_amdgcn_readfirstlane(next_pop);
-            if (pop >= n_deferred) break;
-            if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
-            (void)render_tile<kStats, 3>(p, lds, wlds, nullptr, nullptr, out, bounce_stack, stats_out, st, (int)defer_list[1 + pop], my_xcc, 0);
-        }
-        if (lane == 0) coop[RT_COOP_CMD] = make_float4(__uint_as_float(0u), 0.0f, 0.0f, 0.0f);     /* exit */
-        __syncthreads();
-    } else {
-        /* a helper: wait for the leader's scans and test this wavefront's share of their leaves */
-        for (;;) {
-            __syncthreads();
-            const float4 cmd = coop[RT_COOP_CMD];
-            const uint32_t scan = __float_as_uint(cmd.x);
-            if (scan == 0u) break;
-            const int base = (int)__float_as_uint(cmd.y);
-            const unsigned long long leaf_mask = (unsigned long long)__float_as_uint(cmd.z) | ((unsigned long long)__float_as_uint(cmd.w) << 32);
-            const float4 r0 = coop[RT_COOP_RAY0 + lane], r1 = coop[RT_COOP_RAY1 + lane];
-            const V3 o = xyz(r0), d = xyz(r1);
-            const V3 inv = approx_inverse(d);
-            const uint32_t state = __float_as_uint(r1.w);
-            if (scan == 1u) {
-                float best = r0.w;
-                int best_idx = state == RT_COOP_IDLE ? -1 : (int)state;
-                near_leaf_share<kStats>(lds, lds + p.near_items_off, base, leaf_mask, my_wave, n_waves, state != RT_COOP_IDLE,
-                                        o, d, inv, &best, &best_idx, st);
-                reinterpret_cast<float2 *>(coop + RT_COOP_PART)[my_wave * 64 + lane] = make_float2(best, __int_as_float(best_idx));
-            } else {
-                const bool blocked = shadow_leaf_share<kStats>(lds, lds + p.shadow_items_off, base, leaf_mask, my_wave, n_waves,
-                                                               state == RT_COOP_IDLE, o, d, inv, r0.w, st);
-                const unsigned long long verdict = __builtin_amdgcn_ballot_w64(blocked && state != RT_COOP_IDLE);
-                if (lane == 0) {
-                    uint32_t *part = reinterpret_cast<uint32_t *>(coop + RT_COOP_PART);
-                    part[my_wave * 128] = (uint32_t)verdict;
-                    part[my_wave * 128 + 1] = (uint32_t)(verdict >> 32);
-                }
-            }
-            __syncthreads();
-        }
-    }
-  } else {
+  {
     /* HEAVY tiles first, one per workgroup: the tiles on the horizon line of a scene with clustered sphere runs keep
      * ONE wavefront busy for a millisecond or more (their shadow rays start tens of thousands of units away, where
      * the reference's float sphere test is so coarse that every sphere is a legitimate candidate: 10 scans x 64
@@ -1958,7 +1756,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * with clustered sphere runs, whose tiles take from tens of microseconds to milliseconds: a tile asked for
      * ahead of a long one waits for it while other wavefronts idle (a strip's timeline showed tiles STARTING a
      * millisecond after the queues had run dry); there the next tile is asked for when this one is done */
-    const bool ask_ahead = !(kClusters || kMayDefer || kStats) || p.n_clusters == 0;     /* the plain kernels: always */
+    const bool ask_ahead = !(kClusters || kStats) || p.n_clusters == 0;     /* the plain kernels: always */
     int steal = 0, next_pop = 0;
     bool fresh = true;                 /* the current queue has not been asked yet */
     for (;;) {
@@ -2023,10 +1821,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             reinterpret_cast<unsigned long long *>(p.timeline)[(size_t)wave * RT_TIMELINE_WORDS] = __builtin_amdgcn_s_memrealtime();
 #endif
         const int tile_number = here(wave);
-        if (render_tile<kStats, kFast ? 6 : kMayDefer ? 2 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal)) {
-            /* the tile deferred itself: the second pass renders it */
-            if (lane == 0) defer_list[1u + atomicAdd(&defer_list[0], 1u)] = (unsigned int)wave;
-        }
+        render_tile<kStats, kFast ? 6 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal);
 #ifdef RT_TIMELINE
         if (p.timeline != 0ull && lane == 0) {                   /* ... when it was done, and by whom */
             unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.timeline) + (size_t)tile_number * RT_TIMELINE_WORDS;
@@ -2064,115 +1859,80 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
  * is the first kernel argument): handed to the body as a by-value argument, its ~70 dwords are
  * all loaded at kernel entry and stay live in scalar registers, which left the scans to spill 85
  * SGPRs to VGPR lanes (v_writelane / v_readlane plus their wait states in the loops); read on
- * demand (s_load through the scalar cache) the kernel spills 22 and needs no scratch. */
+ * demand (s_load through the scalar cache) the kernel spills a handful and needs next to no scratch. */
 #define RT_PARAMS_FROM_KERNARG(name, by_value)                                                      \
     (void)by_value;                                                                                 \
     const RtParams &name = *(const RtParams *)(__builtin_amdgcn_kernarg_segment_ptr())
 
-/* 72 VGPRs: seven wavefronts per SIMD where LDS allows (the bounce stack keeps
- * its LDS place up to six workgroups per CU, RT_STACK_LDS_SHARE) */
+/* All render kernels share one signature.  `help_area`: the clustered-scene kernels' HELP areas (128 quads of
+ * global memory per workgroup for the rays a wavefront publishes at its workgroup's desk); unused by the others. */
+#define RT_KERNEL_ARGS                                                                                            \
+    const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,                      \
+    unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack, unsigned int *__restrict__ help_area
+#define RT_KERNEL_ARGS_STATS                                                                                      \
+    const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,                      \
+    unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,                                   \
+    unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ help_area
+
+/* Scenes without clustered sphere runs, FAST tables (the built-in scene: the bench headline).  72 VGPRs: seven
+ * wavefronts per SIMD where LDS allows (the bounce stack keeps its LDS place up to seven workgroups per CU,
+ * RT_STACK_LDS_SHARE) */
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 7
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
-rt_render_kernel(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                 unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                 unsigned int *__restrict__ defer_list) {
+rt_render_kernel(RT_KERNEL_ARGS) {
 #ifdef RT_FAST_PARAMS_BY_VALUE
     const RtParams &p = p_in_kernarg;
 #else
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
 #endif
-    render_body<false, false, false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+    render_body<false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
 }
 
 /* the same over the two item tables: option "fast" = 0, and option "cull" = 0 (the plain in-order scans) */
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
-rt_render_kernel_items(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                       unsigned int *__restrict__ defer_list) {
+rt_render_kernel_items(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<false, false, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+    render_body<false>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
 }
 
 /* scenes whose tables are large (or do not fit LDS at all): the tables stay in global memory */
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
-rt_render_kernel_large(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                       unsigned int *__restrict__ defer_list) {
+rt_render_kernel_large(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+    render_body<false, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
 }
 
-/* scenes with clustered sphere runs (PAIRS, NEAREST PAIRS): 80 registers, six wavefronts per SIMD -- at 72 the
- * colour a finished lane holds across the bounce loop was spilled (0.8-1.3 GB of scratch traffic per 256-sphere-grid
- * frame) for no measurable gain in speed */
+/* scenes with clustered sphere runs (PAIRS, NEAREST PAIRS, HELP, HEAVY tiles): 80 registers, six wavefronts per SIMD */
 #ifndef RT_WAVES_PER_SIMD_CLUSTERS
 #define RT_WAVES_PER_SIMD_CLUSTERS 6
 #endif
 extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_CLUSTERS)
-rt_render_kernel_clusters(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                          unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                          unsigned int *__restrict__ defer_list) {
+rt_render_kernel_clusters(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+    render_body<false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
 }
 
 /* the same with the registers of five wavefronts per SIMD, for scenes whose tables leave room for no more than
- * five workgroups per CU anyway (the 1 024-sphere grid: 31.5 KB): no spills, hence no scratch traffic */
+ * five workgroups per CU anyway (the 1 024-sphere grid: 31.5 KB); the pair flush tests four members abreast here */
 extern "C" __global__ void __launch_bounds__(256, 5)
-rt_render_kernel_clusters_wide(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                               unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                               unsigned int *__restrict__ defer_list) {
+rt_render_kernel_clusters_wide(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<false, false, false, false, true, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
+    render_body<false, false, true, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
 }
 
-/* the first pass for scenes whose tiles may defer themselves (clustered sphere runs) ... */
-#ifndef RT_WAVES_PER_SIMD_DEFERRING
-#define RT_WAVES_PER_SIMD_DEFERRING 5
-#endif
-extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_DEFERRING)
-rt_render_kernel_deferring(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                           unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                           unsigned int *__restrict__ defer_list) {
-    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
-}
-
-/* ... and the second pass: the deferred tiles, one per workgroup (of up to 8 wavefronts) at a time */
-#ifndef RT_SECOND_MIN_BLOCKS
-#define RT_SECOND_MIN_BLOCKS 1
-#endif
-extern "C" __global__ void __launch_bounds__(512, RT_SECOND_MIN_BLOCKS)
-rt_render_kernel_second(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                        unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                        unsigned int *__restrict__ defer_list) {
-    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<false, true, false>(p, image, out, tile_counter, bounce_stack, nullptr, defer_list);
-}
-
-/* the counting builds: same arithmetic and control flow plus work counters */
+/* the counting builds (rt_render_stats): same arithmetic and control flow plus work counters.  One for the item
+ * tables -- with and without clustered runs: the clustered-scene body, which is the plain one when a scene has no
+ * leaves -- and one for the FAST tables */
 extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_stats(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                       unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                       unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
+rt_render_kernel_stats(RT_KERNEL_ARGS_STATS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<true, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
+    render_body<true, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, help_area);
 }
 
 extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_fast_stats(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                            unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                            unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
+rt_render_kernel_fast_stats(RT_KERNEL_ARGS_STATS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<true, false, false, false, false, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
-}
-
-extern "C" __global__ void __launch_bounds__(512)
-rt_render_kernel_second_stats(const RtParams p_in_kernarg, const float4 *__restrict__ image, float *__restrict__ out,
-                              unsigned int *__restrict__ tile_counter, float4 *__restrict__ bounce_stack,
-                              unsigned long long *__restrict__ stats_out, unsigned int *__restrict__ defer_list) {
-    RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
-    render_body<true, true, false>(p, image, out, tile_counter, bounce_stack, stats_out, defer_list);
+    render_body<true, false, false, false, true>(p, image, out, tile_counter, bounce_stack, stats_out, help_area);
 }

@@ -119,10 +119,6 @@
 /* the workgroup's HELP desk: words of LDS (rt_kernel.hip) */
 enum { RT_DESK_STATE = 0, RT_DESK_CURSOR, RT_DESK_INSIDE, RT_DESK_FINISHED, RT_DESK_MASK_LO, RT_DESK_MASK_HI,
        RT_DESK_BASE, RT_DESK_VERDICT_LO, RT_DESK_VERDICT_HI, RT_DESK_BROKEN, RT_DESK_DEDICATED, RT_DESK_PHASE, RT_DESK_WORDS = 12 };
-#ifndef RT_DEFER_LEAVES
-#define RT_DEFER_LEAVES 32           /* automatic: a scan with this many candidate leaves, most of them needed by some ray, defers its tile */
-#endif
-#define RT_COOP_QUADS(waves) (129 + 32 * (waves))   /* LDS of the second pass's workgroups: 64 + 64 ray quads, a command, 32 per wavefront */
 
 #define RT_NEAR_CULL_MIN_ITEMS 8     /* below this many items the nearest scan skips the bundle cull */
 #define RT_SHADOW_CULL_MIN_ITEMS 8   /* below this many shadow items the wavefront skips the bundle-box cull */
@@ -153,17 +149,10 @@ typedef struct RtParams {
     int32_t tiles_x;                     /* wavefront tiles along x */
     int32_t n_tiles;                     /* total wavefront tiles   */
     int32_t stack_off;                   /* quad offset of the bounce stack's LDS levels: behind the tables, or 0 when the tables stay in global memory */
-    int32_t stack_stride;                /* threads that keep a bounce stack per workgroup: all of them, or 64 (the leader) in the second pass */
+    int32_t stack_stride;                /* threads that keep a bounce stack per workgroup (all of them) */
     int32_t stack_lds_levels;            /* bounce levels below this keep their stack entries in LDS (behind the tables), the others in HBM */
     int32_t first_macro_row;             /* the tile queues start at this macro row and wrap around ... */
     int32_t rows_downwards;              /* ... upwards (0) or downwards (1)                           */
-    /* Deferred tiles (rt_kernel.hip, "DEFERRED tiles").  The first pass renders every tile, except that a
-     * tile one of whose scans is left with >= defer_leaves candidate leaves by its bundle cull (0: never),
-     * most of them needed by some ray, abandons itself and appends its number to the defer list
-     * {count, tile, tile, ...}.  The second pass (another launch on the same stream) renders the listed
-     * tiles one per WORKGROUP: wavefront 0 leads, all wavefronts share the candidate leaves of its scans
-     * through the LDS area at quad coop_off (behind the tables and the bounce stack). */
-    int32_t defer_leaves, coop_off;
     /* HELP (rt_kernel.hip): the workgroup's desk, RT_DESK_WORDS words of LDS at quad desk_off; help_rays_quads != 0:
      * the launch carries 128 quads of global memory per workgroup for the published rays (0: no helping) */
     int32_t desk_off, help_rays_quads;
