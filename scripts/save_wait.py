@@ -31,12 +31,14 @@ def last_dispatch(path, want="rt_render_kernel"):
 summary = {}
 for w in workloads:
     c, kernel = {}, None
-    for p in "ABC":
+    passes = {}
+    for p in "ABCD":
         g = sorted(glob.glob(os.path.join(src, f"wait_{w}_{p}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
         if not g:
             continue
         k, d = last_dispatch(g[-1])
         kernel = kernel or k
+        passes[p] = d
         c.update(d)
     if not c:
         continue
@@ -66,6 +68,9 @@ for w in workloads:
         "ifetch_level_per_ifetch": g("SQ_IFETCH_LEVEL") / g("SQ_IFETCH") if g("SQ_IFETCH") else None,
         "lds_bank_conflict_share_of_idx_active": g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else None,
         "inst_level_lds_per_lds_inst": g("SQ_INST_LEVEL_LDS") / g("SQ_INSTS_LDS") if g("SQ_INSTS_LDS") else None,
+        # pass D (both counters from the same pass): lanes active per vector instruction / 64 = rocprof's VALUUtilization
+        "valu_lane_utilisation": (passes["D"]["SQ_THREAD_CYCLES_VALU"] / (passes["D"]["SQ_ACTIVE_INST_VALU"] * 64.0)
+                                  if "D" in passes and passes["D"].get("SQ_ACTIVE_INST_VALU") else None),
     }
     summary[w] = s
 json.dump(summary, open(os.path.join(P, f"{tag}_pmc_wait_summary.json"), "w"), indent=1)
