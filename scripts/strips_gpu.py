@@ -26,3 +26,17 @@ for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8), ("grid32-noshadow"
         ts = [t(*strip_bounds(S, N, k)[:2]) for k in range(N)]
         print(f"{name:8s} N={N}: full {full:.3f} ms; strips " + " ".join(f"{x:.3f}" for x in ts) +
               f"; max {max(ts):.3f} -> render-bound speedup {full / max(ts):.2f}x", flush=True)
+        # what bench.py does at N > 1: re-cut the strips by the measured cost (balanced_bounds, nothing to send in this
+        # render-only model), twice; boundaries on multiples of 16 columns
+        import numpy as np
+        from tilecoderaytracer_amd.distributed import balanced_bounds
+        bounds = [strip_bounds(S, N, k)[:2] for k in range(N)]
+        for _ in range(2):
+            cost = np.zeros(S)
+            for (a, b), tk in zip(bounds, ts):
+                cost[a:b] = tk / max(b - a, 1)
+            bounds = balanced_bounds(S, N, cost, 0.0)
+            bounds = [(min(S, (a + 8) // 16 * 16) if a else 0, S if b == S else min(S, (b + 8) // 16 * 16)) for a, b in bounds]
+            ts = [t(a, b) if b > a else 0.0 for a, b in bounds]
+        print(f"{name:8s} N={N}: strips cut by measured cost " + "/".join(str(b - a) for a, b in bounds) + " columns: " +
+              " ".join(f"{x:.3f}" for x in ts) + f"; max {max(ts):.3f} -> render-bound speedup {full / max(ts):.2f}x", flush=True)
