@@ -1544,6 +1544,10 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                 }
                 if (p.cull != 0 && p.n_shadow_items >= RT_SHADOW_CULL_MIN_ITEMS) shading_point_bundle(box_lo, box_hi, &bundle_centre, &bundle_half);
             }
+            /* The reference re-normalises the hit's normal twice per light (renormalize3(), below); whether that is the
+             * identity -- N.N rounds to exactly 1 in every shading lane, the usual case -- does not depend on the light:
+             * asked once per level here instead of twice per light there. */
+            const bool normals_are_unit = !wave_any(shade && (N.x * N.x + N.y * N.y + N.z * N.z) != 1.0f);
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
@@ -1563,7 +1567,7 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                     const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
                     const V3 object_color = entry_colour(p, lds, m0, __float_as_uint(m1.w), texsel);
                     const float diffuse_factor = m0.w, specular_factor = m1.x;
-                    const V3 normal_dir = renormalize3(N);   /* CollisionObject ctor: Ray(point, normal) re-normalises, src/SceneObject.h:62 */
+                    const V3 normal_dir = normals_are_unit ? N : renormalize3(N);   /* CollisionObject ctor: Ray(point, normal) re-normalises, src/SceneObject.h:62 */
                     const V3 light_color = xyz(l1);
                     /* cosineShade, :654-701 */
                     if (diffuse_factor > (float)0) {
@@ -1579,7 +1583,7 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                         C.z = (C.z > 1.0f) ? 1.0f : C.z;
                     }
                     /* specular, :561-588 */
-                    const V3 Nn = renormalize3(normal_dir);  /* third normalisation, :566-567 */
+                    const V3 Nn = normals_are_unit ? normal_dir : renormalize3(normal_dir);  /* third normalisation, :566-567 */
                     const V3 R = sub3(light_ray, scale3(Nn, 2.0f * dot3(light_ray, Nn)));
                     const float dot = dot3(d, R);
                     if (dot > (float)0) {
