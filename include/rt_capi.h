@@ -257,7 +257,7 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   with direct test records (FAST tables), 0 = the two item tables
  *   "tight_planes"  0 = plane items get the (much larger) padding of sphere items
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
- *   "cluster_leaf", "cluster_group", "leaf_items"   sphere clustering */
+ *   "cluster_leaf"  spheres per leaf of a clustered run (default 16; 0 = no clustering) */
 int rt_set_option(rt_scene *scene, const char *key, int value);
 
 int         rt_device_count(int *count);

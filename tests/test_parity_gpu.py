@@ -422,13 +422,12 @@ def test_adversarial_scenes(oracle, seed):
     assert_same(Renderer(host).render(96, 64, 5), orc.render(96, 64, 5), f"adversarial seed {seed}")
 
 
-@pytest.mark.parametrize("leaf,group", [(0, 8), (4, 2), (8, 4), (16, 8), (32, 16)])
-def test_cluster_parameters_do_not_change_results(oracle, leaf, group):
+@pytest.mark.parametrize("leaf", [0, 4, 8, 16, 32])
+def test_cluster_parameters_do_not_change_results(oracle, leaf):
     host = _adversarial(HostScene.empty(), 77)
     r = Renderer(host)
     r.set_option("cluster_leaf", leaf)
-    r.set_option("cluster_group", group)
-    assert_same(r.render(80, 48, 4), _adversarial(oracle.OracleScene(), 77).render(80, 48, 4), f"leaf {leaf} group {group}")
+    assert_same(r.render(80, 48, 4), _adversarial(oracle.OracleScene(), 77).render(80, 48, 4), f"leaf {leaf}")
 
 
 def test_aa_fast_path_can_be_switched_off(oracle):
@@ -651,7 +650,7 @@ def test_failed_option_leaves_the_handle_usable(oracle):
     from tilecoderaytracer_amd import RtError
     want = oracle.OracleScene.two_mirrors().render(24, 24, 3)
     r = Renderer(HostScene.two_mirrors())
-    for key, value in (("cluster_leaf", 0), ("leaf_items", 0), ("cluster_group", 1), ("cull", 0)):
+    for key, value in (("cluster_leaf", 0), ("cluster_leaf", 4), ("cull", 0)):
         try:
             r.set_option(key, value)
         except RtError:

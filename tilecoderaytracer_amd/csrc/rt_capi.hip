@@ -92,12 +92,10 @@ struct rt_scene {
     int pairs_opt = 1;            /* scenes with clustered runs: the kernel that compacts (ray, leaf) pairs (0: the plain kernel) */
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
-    int leaf_items_opt = 1;       /* clustered runs appear in the item tables leaf by leaf (0: group by group) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
     int fast_opt = 1;             /* scenes without clustered runs: the kind-sorted item list with direct records (FAST tables); 0: the two item tables */
     int tight_planes = 1;         /* plane items: boxes padded for a plane's rounding only (RT_ITEM_TIGHT); 0: the sphere padding */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
-    int cluster_group = 8;        /* leaves per group (second level of the cluster hierarchy)          */
     int cull_opt = 1;             /* 0: plain in-order scans -- no bundle cull, no nearest-first exit, no clustering, no AA route */
     int n_clusters = 0;
     /* tile queue heads, one per in-flight launch (same ring as the events) */
@@ -209,7 +207,7 @@ int pack_scene(rt_scene *s) {
     const int cluster_leaf = s->cull_opt ? s->cluster_leaf : 0;
     const bool aa_planes = s->cull_opt && s->aa_planes;
 
-    std::vector<Quad> geom, lights, mats, texs, clusters;
+    std::vector<Quad> geom, lights, mats, texs;
     std::vector<uint32_t> objinfo((size_t)n, 0u), cidx;
     std::vector<int> geom_off((size_t)n, 0), mat_of((size_t)n, 0);
     std::map<std::vector<uint32_t>, int> mat_index;
@@ -276,8 +274,6 @@ int pack_scene(rt_scene *s) {
     std::vector<int> aa_rec_of((size_t)n, -1);       /* their AA test record (quad offset within aa_recs) */
     std::vector<int> aa_cls_of((size_t)n, -1);
     std::vector<char> clustered((size_t)n, 0);
-    struct GroupItem { float lo[3], hi[3]; uint32_t leaf_index, n_leaves, cidx_first; bool in_shadow; };
-    std::vector<GroupItem> group_items;
     struct LeafItem { float lo[3], hi[3]; uint32_t member_off, count, cidx_slot; bool in_shadow; };
     std::vector<LeafItem> leaf_items;
     std::vector<Quad> shadow_items, near_items;
@@ -298,42 +294,18 @@ int pack_scene(rt_scene *s) {
             for (int i = 0; i < sp.count; ++i) ids[(size_t)i] = first + i;
             std::vector<Leaf> leaves;
             split_leaves(objs, ids, cluster_leaf, leaves);
-            /* leaves come out of the k-d split in spatial order: every `group`
-             * consecutive leaves form a group with its own bounding ball */
-            const int G = std::max(1, s->cluster_group);
-            const int n_groups = ((int)leaves.size() + G - 1) / G;
-            const int cidx_first = (int)cidx.size();
-            for (int gi = 0; gi < n_groups; ++gi) {
-                const int l0 = gi * G, l1 = std::min((int)leaves.size(), l0 + G);
-                std::vector<int> all;
-                for (int l = l0; l < l1; ++l) all.insert(all.end(), leaves[(size_t)l].members.begin(), leaves[(size_t)l].members.end());
-                std::vector<Leaf> ball;
-                make_leaf(objs, all, ball);
-                /* item for the group: geometry offset = its first leaf record (index into the leaf
-                 * section, made absolute below), count = its leaves */
-                GroupItem gi_rec;
-                for (int k = 0; k < 3; ++k) { gi_rec.lo[k] = ball[0].lo[k]; gi_rec.hi[k] = ball[0].hi[k]; }
-                gi_rec.leaf_index = (uint32_t)(clusters.size() / RT_CLUSTER_QUADS);
-                gi_rec.n_leaves = (uint32_t)(l1 - l0);
-                gi_rec.cidx_first = (uint32_t)cidx_first;
-                gi_rec.in_shadow = in_shadow_all;
-                group_items.push_back(gi_rec);
-                for (int l = l0; l < l1; ++l) {
-                    const Leaf &L = leaves[(size_t)l];
-                    const int member_off = (int)geom.size();
-                    const int slot = (int)cidx.size() - cidx_first;
-                    for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); clustered[(size_t)i] = 1; }
-                    clusters.push_back({{L.lo[0], L.lo[1], L.lo[2],
-                                         bits_to_float((uint32_t)member_off | ((uint32_t)L.members.size() << 16))}});
-                    clusters.push_back({{L.hi[0], L.hi[1], L.hi[2], bits_to_float((uint32_t)slot)}});
-                    LeafItem li;
-                    for (int k = 0; k < 3; ++k) { li.lo[k] = L.lo[k]; li.hi[k] = L.hi[k]; }
-                    li.member_off = (uint32_t)member_off;
-                    li.count = (uint32_t)L.members.size();
-                    li.cidx_slot = (uint32_t)(cidx_first + slot);
-                    li.in_shadow = in_shadow_all;
-                    leaf_items.push_back(li);
-                }
+            /* the leaves come out of the k-d split in spatial order; each becomes one item of both scans */
+            for (const Leaf &L : leaves) {
+                const int member_off = (int)geom.size();
+                const int slot = (int)cidx.size();
+                for (int i : L.members) { emit_geometry(i); cidx.push_back((uint32_t)i); clustered[(size_t)i] = 1; }
+                LeafItem li;
+                for (int k = 0; k < 3; ++k) { li.lo[k] = L.lo[k]; li.hi[k] = L.hi[k]; }
+                li.member_off = (uint32_t)member_off;
+                li.count = (uint32_t)L.members.size();
+                li.cidx_slot = (uint32_t)slot;
+                li.in_shadow = in_shadow_all;
+                leaf_items.push_back(li);
             }
             n_clusters += (int)leaves.size();
         } else if (sp.kind == RT_KIND_FINITE_PLANE && aa_planes) {
@@ -380,8 +352,6 @@ int pack_scene(rt_scene *s) {
     std::memset(&b, 0, sizeof(b));
     std::vector<Quad> image;
     image.insert(image.end(), geom.begin(), geom.end());
-    const int clusters_off = (int)image.size();
-    image.insert(image.end(), clusters.begin(), clusters.end());
     const int aa_off = (int)image.size();
     image.insert(image.end(), aa_recs.begin(), aa_recs.end());
     /* Scene-index tables of the clustered / class-sorted runs */
@@ -495,14 +465,6 @@ int pack_scene(rt_scene *s) {
                     box_item(out, lo, hi, (uint32_t)RT_KIND_FINITE_PLANE | tight | (full << 16), word1, unbounded);
             }
         };
-        auto group_item = [&](std::vector<Quad> &out, const GroupItem &g) {
-            Quad q0 = {{g.lo[0], g.lo[1], g.lo[2],
-                        bits_to_float((uint32_t)RT_KIND_SPHERE_CLUSTERED | (g.n_leaves << 8) |
-                                      ((uint32_t)(clusters_off + (int)g.leaf_index * RT_CLUSTER_QUADS) << 16))}};
-            Quad q1 = {{g.hi[0], g.hi[1], g.hi[2], bits_to_float((uint32_t)(cidx_off * 4) + g.cidx_first)}};
-            out.push_back(q0);
-            out.push_back(q1);
-        };
         for (int i = 0; i < n; ++i)
             if (!clustered[(size_t)i]) object_item(near_items, i);
         auto leaf_item = [&](std::vector<Quad> &out, const LeafItem &l) {
@@ -513,21 +475,12 @@ int pack_scene(rt_scene *s) {
             out.push_back(q1);
         };
         b.near_first_leaf = (int)(near_items.size() / 2);
-        if (s->leaf_items_opt) {
-            for (const LeafItem &l : leaf_items) leaf_item(near_items, l);
-        } else {
-            for (const GroupItem &g : group_items) group_item(near_items, g);
-        }
+        for (const LeafItem &l : leaf_items) leaf_item(near_items, l);
         for (int i = sb; i < se; ++i)
             if (!objs[i].is_light && !clustered[(size_t)i]) object_item(shadow_items, i);
         b.shadow_first_leaf = (int)(shadow_items.size() / 2);
-        if (s->leaf_items_opt) {
-            for (const LeafItem &l : leaf_items)
-                if (l.in_shadow) leaf_item(shadow_items, l);
-        } else {
-            for (const GroupItem &g : group_items)
-                if (g.in_shadow) group_item(shadow_items, g);
-        }
+        for (const LeafItem &l : leaf_items)
+            if (l.in_shadow) leaf_item(shadow_items, l);
         if (fast) {
             auto kind_rank = [&](int i) {
                 if (aa_rec_of[(size_t)i] >= 0) return aa_cls_of[(size_t)i];                 /* 0..2: AA rectangles by normal axis */
@@ -1261,7 +1214,6 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         }
         return (int)RT_OK;
     };
-    if (!std::strcmp(key, "leaf_items")) return repack_with(s->leaf_items_opt, value != 0);
     if (!std::strcmp(key, "aa_planes")) return repack_with(s->aa_planes, value != 0);
     if (!std::strcmp(key, "tight_planes")) return repack_with(s->tight_planes, value != 0);
     if (!std::strcmp(key, "fast")) return repack_with(s->fast_opt, value != 0);
@@ -1270,10 +1222,9 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return repack_with(s->tables_opt, value);
     }
     if (!std::strcmp(key, "cull")) return repack_with(s->cull_opt, value != 0);
-    if (!std::strcmp(key, "cluster_leaf") || !std::strcmp(key, "cluster_group")) {
-        const bool leaf = !std::strcmp(key, "cluster_leaf");
-        if (value < (leaf ? 0 : 1) || value > 255) return fail(RT_ERR_INVALID, "cluster_leaf in [0,255], cluster_group in [1,255]");
-        return repack_with(leaf ? s->cluster_leaf : s->cluster_group, value);
+    if (!std::strcmp(key, "cluster_leaf")) {
+        if (value < 0 || value > 255) return fail(RT_ERR_INVALID, "cluster_leaf must be in [0, 255]");
+        return repack_with(s->cluster_leaf, value);
     }
     return fail(RT_ERR_INVALID, std::string("unknown option: ") + key);
 }

@@ -837,28 +837,6 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                         if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
                     }
                 }
-            } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves; bits1 = its Scene-index table */
-                const int n_leaves = (int)((bits >> 8) & 255u);
-                st_wave(st, ST_WAVE_BOX_TESTS);
-                if (!wave_any(active && box_needed(i0, i1, o, inv, best))) continue;
-                for (int c = 0; c < n_leaves; ++c) {
-                    const float4 c0 = g[c * RT_CLUSTER_QUADS], c1 = g[c * RT_CLUSTER_QUADS + 1];
-                    st_wave(st, ST_WAVE_BOX_TESTS);
-                    const bool lane_needs = active && box_needed(c0, c1, o, inv, best);
-                    if (!wave_any(lane_needs)) continue;
-                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
-                    const int n = (int)(__float_as_uint(c0.w) >> 16);
-                    const uint32_t *ids = lds_u32 + bits1 + __float_as_uint(c1.w);
-#pragma unroll 2
-                    for (int i = 0; i < n; ++i) {
-                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
-                        sphere_distance(m[i], o, d, &hit, &t);
-                        if (wave_any(hit)) {
-                            const int member = (int)ids[i];
-                            if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
-                        }
-                    }
-                }
             } else if (kind == RT_KIND_INFINITE_PLANE) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 infinite_plane_distance(g[0], o, d, best, &hit, &t);
@@ -1149,24 +1127,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                 const unsigned long long needers = __builtin_amdgcn_ballot_w64(lane_needs);
                 if (needers == 0ull) continue;
                 take_leaf(bits, lane_needs, needers);
-            } else if (kind == RT_KIND_SPHERE_CLUSTERED) {          /* a group of leaves of a clustered run */
-                const int n_leaves = (int)((bits >> 8) & 255u);
-                st_wave(st, ST_WAVE_BOX_TESTS);
-                if (!wave_any(!blocked && box_needed(i0, i1, o, inv, dist_to_light))) continue;   /* per-ray test of the group box */
-                for (int c = 0; c < n_leaves; ++c) {
-                    const float4 c0 = g[c * RT_CLUSTER_QUADS], c1 = g[c * RT_CLUSTER_QUADS + 1];
-                    st_wave(st, ST_WAVE_BOX_TESTS);
-                    const bool lane_needs = !blocked && box_needed(c0, c1, o, inv, dist_to_light);
-                    if (!wave_any(lane_needs)) continue;
-                    const float4 *m = lds + (__float_as_uint(c0.w) & 0xFFFFu);
-                    const int n = (int)(__float_as_uint(c0.w) >> 16);
-#pragma unroll 2
-                    for (int i = 0; i < n; ++i) {
-                        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
-                        sphere_distance(m[i], o, d, &hit, &t);
-                        blocked = blocked || (hit && t < dist_to_light);
-                    }
-                }
             } else if (kind == RT_KIND_INFINITE_PLANE) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 infinite_plane_distance(g[0], o, d, dist_to_light, &hit, &t);
@@ -1822,8 +1782,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
          * few lines cost registers: six more spilled in the plain kernel, twenty in the clustered-scene one) */
         if (p.timeline != 0ull && lane == 0)
             reinterpret_cast<unsigned long long *>(p.timeline)[(size_t)wave * RT_TIMELINE_WORDS] = __builtin_amdgcn_s_memrealtime();
-#endif
         const int tile_number = here(wave);
+#endif
         render_tile<kStats, kFast ? 6 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal);
 #ifdef RT_TIMELINE
         if (p.timeline != 0ull && lane == 0) {                   /* ... when it was done, and by whom */

@@ -15,9 +15,6 @@
  *                (anchor = SceneObject::origin for the infinite plane,
  *                 plane_origin for the finite plane: the point texture/bounds
  *                 coordinates are measured from)
- *   leaves     2 quads per leaf of a clustered sphere run:
- *                {box lo.xyz, bits(member geometry offset | member count << 16)},
- *                {box hi.xyz, bits(first slot in the run's cidx table)}
  *   aa         2 quads per axis-aligned finite plane (its fast test record):
  *                {dto, sn, sh, sv}, {po_a, po_b, h_dist, v_dist}
  *                in coordinates permuted to (normal, horizontal, vertical) axis
@@ -33,10 +30,8 @@
  *                bits 0-15 geometry offset (quads), 16-17 kind, 20-31 material row
  *
  * Clustered sphere runs.  A run of >= 4*leaf consecutive spheres is regrouped
- * (k-d median split of the centres) into spatial leaves of <= leaf spheres, and
- * every `group` consecutive leaves (they come out in spatial order) form a
- * GROUP.  Leaf and group boxes are axis-aligned, inflated, and contain every
- * member sphere.  Members are visited out of Scene order; the nearest hit
+ * (k-d median split of the centres) into spatial leaves of <= leaf spheres.  A leaf's
+ * box is axis-aligned, inflated, and contains every member sphere.  Members are visited out of Scene order; the nearest hit
  * stays exact because ties are broken on the Scene index (the lexicographic
  * minimum of (distance, index) is what an in-order scan with a strict `<`
  * computes).
@@ -45,8 +40,7 @@
  * (src/RayTracer.cpp:50-89) and the shadow scan over the non-light objects of
  * the scan range (src/RayTracer.cpp:709-739) -- walk a table of ITEMS: one per
  * object that is not in a clustered run, in Scene index order, then one per
- * LEAF of each clustered run (or, with the "leaf_items" option off, one per
- * group).  2 quads per item:
+ * LEAF of each clustered run.  2 quads per item:
  *   {box lo.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
  *   {box hi.xyz, bits(Scene index | quad offset of the full 5-quad plane record << 12)}
  * kind = RT_KIND_SPHERE / _INFINITE_PLANE / _FINITE_PLANE;
@@ -54,10 +48,7 @@
  *        offset = its aa record);
  *        RT_KIND_SPHERE_LEAF for a leaf (count = its members, geometry offset =
  *        its first member sphere, second word = u32 index of its members'
- *        Scene indices);
- *        RT_KIND_SPHERE_CLUSTERED for a group (count = its leaves, geometry
- *        offset = its first leaf record, second word = u32 index of the run's
- *        cidx table).
+ *        Scene indices).
  * The box (inflated on the host) contains the object; an infinite plane's box
  * is all of space.  The wavefront culls 64 item boxes at once, one per lane
  * (rt_kernel.hip: nearest_hit_items, in_shade).
@@ -72,12 +63,9 @@
 #define RT_LIGHT_QUADS  2
 #define RT_MAT_QUADS    2
 #define RT_TEX_QUADS    2
-#define RT_CLUSTER_QUADS 2
 
 /* item kinds: RT_KIND_* of rt_capi.h (0 sphere, 1 infinite plane, 2 finite
- * plane), plus a group of leaves of a clustered sphere run ... */
-#define RT_KIND_SPHERE_CLUSTERED 3
-/* ... and axis-aligned finite planes: kind = 4 + axis of the normal (0 x, 1 y, 2 z).
+ * plane), plus axis-aligned finite planes: kind = 4 + axis of the normal (0 x, 1 y, 2 z).
  * Their 2-quad test record lists the two in-plane axes in cyclic order after the
  * normal's: {dto, sign_n, sign_a, sign_b}, {origin_a, origin_b, extent_a, extent_b}.
  * The full 5-quad record of each plane is kept too (winner record, non-finite rays). */
