@@ -498,7 +498,7 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
 #define RT_COOP_IDLE 0x80000000u     /* state word of a published ray whose lane has no shadow ray (or is blocked already) */
 
 /* HELP (clustered scenes, whole frames and wide strips: rt_render_kernel_clusters*).  A wavefront that has run
- * out of tiles does not leave: it waits at its workgroup's DESK (ten words of LDS) until all the workgroup's
+ * out of tiles does not leave: it waits at its workgroup's DESK (RT_DESK_WORDS words of LDS) until all the workgroup's
  * wavefronts are out of tiles, and meanwhile serves the others.  A wavefront whose shadow scan is left with
  * p.help_leaves or more candidate leaves, and that sees a colleague waiting, publishes its 64 rays (global
  * memory, 2 KB per workgroup) and the candidate mask at the desk and opens it; everybody -- the owner included --
