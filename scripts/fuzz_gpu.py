@@ -7,7 +7,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
 import oracle_lib                                   # noqa: E402
-from scene_gen import build_random, build_sphere_field   # noqa: E402
+from scene_gen import build_random, build_room, build_sphere_field   # noqa: E402
 from tilecoderaytracer_amd import HostScene, Renderer    # noqa: E402
 
 kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
@@ -15,7 +15,10 @@ first, count = int(kv.get("first_seed", 1000)), int(kv.get("count", 200))
 bad, t0 = [], time.time()
 for seed in range(first, first + count):
     rng = np.random.RandomState(seed)
-    if seed % 4 == 0:
+    if seed % 4 == 1:                   # axis-aligned rooms: rectangles, slabs, lights hugging surfaces, scales (round 3's culls)
+        mk = lambda s: build_room(s, seed)
+        W, H, depth = int(rng.randint(8, 120)), int(rng.randint(8, 120)), int(rng.randint(0, 7))
+    elif seed % 4 == 0:
         n = int(rng.choice([64, 80, 130, 260]))
         mk = lambda s: build_sphere_field(s, seed, n_spheres=n, spread=float(rng.choice([30.0, 60.0, 200.0])))
         W, H, depth = 40, int(rng.choice([64, 512, 2048])), int(rng.randint(1, 6))

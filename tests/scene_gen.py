@@ -92,3 +92,89 @@ def build_sphere_field(scene, seed, n_spheres=120, spread=60.0):
     scene.set_object_indices(0, 1)
     scene.camera_two_mirrors()
     return scene
+
+
+def build_room(scene, seed):
+    """Axis-aligned rooms: what round 3's culls changed.  Boxes of three-corner rectangles (the reference's makeSceneBox),
+    nested and touching; axis-aligned INFINITE planes on any axis and side (slabs in the culls), lights that hug a surface
+    (1e-3 ... 1e-1 in front of it) or sit exactly in a wall's plane, shading points that start on the surfaces (plane hits
+    are offset 1e-3), a few spheres, everything scaled from 1e-2 to 1e3 and shifted away from the origin -- the culls' slack
+    is relative to distance and magnitude -- seen by the horizontal two-mirrors camera (eye (0,-1,2.5), looking along +y)."""
+    rng = np.random.RandomState(seed)
+    scale = f32(rng.choice([0.01, 0.3, 1.0, 1.0, 7.0, 1000.0]))
+    shift = np.float32(rng.choice([0.0, 0.0, 3.0, 250.0]) * rng.uniform(-1, 1, 3)) if scale <= 7.0 else np.zeros(3, np.float32)
+
+    def pt(x, y, z):                    # a point of the unit-scale layout in front of the camera, scaled about the eye
+        v = np.float32([x, y, z])
+        eye = np.float32([0.0, -1.0, 2.5])
+        w = eye + (v - eye) * np.float32(scale)
+        return tuple(f32(c) for c in (w if scale > 7.0 else w + shift * 0))
+
+    def box(o, dims, **mat):
+        o, dims = np.float32(o), np.float32(dims)
+        c = [o.copy() for _ in range(8)]
+        c[1][0] += dims[0]; c[2][1] += dims[1]; c[3][2] += dims[2]
+        c[4][0] += dims[0]; c[4][1] += dims[1]; c[5][0] += dims[0]; c[5][2] += dims[2]
+        c[6][1] += dims[1]; c[6][2] += dims[2]; c[7] = o + dims
+        for a, b, d in ((0, 3, 2), (0, 3, 1), (0, 1, 2), (7, 4, 6), (7, 4, 5), (7, 5, 6)):
+            i = scene.add_finite_plane_corners(pt(*c[a]), pt(*c[b]), pt(*c[d]))
+            scene.set_color(i, mat.get("color", (0.33, 0.33, 0.33)))
+            if mat.get("reflective"):
+                scene.set_reflective(i, mat["reflective"])
+                scene.set_diffuse(i, mat.get("diffuse", 0.5))
+            if mat.get("specular") is not None:
+                scene.set_specular(i, mat["specular"])
+
+    room_lo, room_hi = np.float32([-7, -3, -1]), np.float32([7, 14.5, 6])     # the eye is inside
+    lights = []
+    for k in range(int(rng.randint(1, 4))):
+        mode = rng.randint(4)
+        p = np.float32([rng.uniform(-6, 6), rng.uniform(2, 13), rng.uniform(0.5, 5)])
+        if mode == 0:                   # hugging a wall of the room
+            axis, side = rng.randint(3), rng.randint(2)
+            gap = np.float32(rng.choice([1e-3, 1e-2, 1e-1]))
+            p[axis] = room_hi[axis] - gap if side else room_lo[axis] + gap
+        elif mode == 1:                 # exactly in a wall's plane (beside the wall's rectangle or on it)
+            axis = rng.randint(3)
+            p[axis] = room_hi[axis]
+        lights.append(p)
+        i = scene.add_sphere(pt(*p), f32(0.15 * scale))
+        scene.set_light(i)
+        scene.set_intensity(i, f32(rng.uniform(0.4, 1.0)))
+    order = ["room", "slab", "table", "inner"] + ["sphere"] * int(rng.randint(0, 7)) + ["plane"] * int(rng.randint(0, 4))
+    rng.shuffle(order)
+    for what in order:
+        if what == "room":
+            box(room_lo, room_hi - room_lo, color=(0.33, 0.33, 0.33), specular=0.0)
+        elif what == "slab":            # a ceiling slab with a gap to the walls, like the reference's scene
+            box((-6, 1.5, 5), (12, 12, 1), color=(0.66, 0.66, 0.66), reflective=0.5, specular=0.5)
+        elif what == "table":
+            o = (f32(rng.uniform(-4, 2)), f32(rng.uniform(3, 9)), 0.0)
+            box(o, (f32(rng.uniform(0.5, 3)), f32(rng.uniform(0.5, 3)), f32(rng.uniform(0.2, 2))), color=(0.2, 0.2, 0.0),
+                reflective=float(rng.choice([0.0, 0.5])), specular=0.2)
+        elif what == "inner":           # a box that touches the floor plane z = 0 and another box's face (coincident surfaces)
+            box((-0.5, 5.0, 0.0), (1, 1, 1), color=(0.2, 0.2, 0.0))
+            box((0.5, 5.0, 0.0), (0.7, 1, 0.5), color=(1, 0, 0), reflective=1.0, diffuse=0.0)
+        elif what == "sphere":
+            i = scene.add_sphere(pt(rng.uniform(-5, 5), rng.uniform(2, 12), rng.uniform(0.3, 4)), f32(rng.uniform(0.2, 1.2) * scale))
+            scene.set_color(i, PALETTE[rng.randint(len(PALETTE))])
+            if rng.rand() < 0.5:
+                scene.set_reflective(i, f32(rng.choice([0.5, 1.0])))
+                scene.set_diffuse(i, f32(rng.choice([0.0, 0.5])))
+        else:                           # an axis-aligned infinite plane: any axis, either side, through or beside the room
+            axis, sign = rng.randint(3), float(rng.choice([-1.0, 1.0]))
+            n = [0.0, 0.0, 0.0]; n[axis] = sign
+            h = [0.0, 0.0, 0.0]; h[(axis + 1) % 3] = 1.0
+            where = np.float32([0, 5, 0])
+            where[axis] = np.float32(rng.choice([-20.0, 40.0, 13.0] if axis == 1 else [0.0, -1.0, 6.0, 3.3, -20.0, 40.0]))   # never across the eye's view
+            i = scene.add_infinite_plane(pt(*where), tuple(n), tuple(h))
+            scene.set_color(i, PALETTE[rng.randint(len(PALETTE))])
+            if rng.rand() < 0.6:
+                scene.set_reflective(i, 0.5)
+                scene.set_diffuse(i, 0.5)
+            if rng.rand() < 0.5:
+                scene.set_checkerboard(i, (1, 1, 1), (0, 0, 0), f32(3 * scale), f32(3 * scale))
+    if rng.rand() < 0.85:
+        scene.set_object_indices(0, 1)
+    scene.camera_two_mirrors()
+    return scene

@@ -163,6 +163,20 @@ def test_random_scenes(oracle, seed):
     assert_same(Renderer(host).render(72, 56, 5), orc.render(72, 56, 5), f"seed {seed}")
 
 
+@pytest.mark.parametrize("seed", range(200, 224))
+def test_axis_aligned_rooms(oracle, seed):
+    """Boxes of axis-aligned rectangles, axis-aligned infinite planes (slabs), lights hugging walls, scales from 1e-2 to
+    1e3: the tight plane boxes and slabs of the culls against the oracle, FAST tables and item tables."""
+    from scene_gen import build_room
+    host, orc = build_room(HostScene.empty(), seed), build_room(oracle.OracleScene(), seed)
+    want = orc.render(88, 72, 5)
+    r = Renderer(host)
+    assert_same(r.render(88, 72, 5), want, f"room seed {seed}")
+    if seed % 3 == 0:
+        r.set_option("fast", 0)
+        assert_same(r.render(88, 72, 5), want, f"room seed {seed}, item tables")
+
+
 def test_partial_shadow_range(oracle):
     """Scene::SetObjectIndices(rank, size) narrows the shadow scan (src/Scene.cpp:486-504)."""
     from scene_gen import build_random

@@ -262,6 +262,12 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_camera_desc *cam, int W, in
     }
     HIP_OR_FAIL(hipSetDevice(0));
     HIP_OR_FAIL(hipMemcpy(out_rgb, m->d_full, image_bytes, hipMemcpyDeviceToHost));
+    /* what the kernels may have had to tell the host (a HELP wait that timed out: the image is exact, the caller is told) */
+    for (int g = 0; g < ngpu; ++g) {
+        rt_timing tm;
+        int rc = rt_get_timing(m->scenes[(size_t)g], &tm);
+        if (rc) return rc;
+    }
     return RT_OK;
 }
 
