@@ -39,5 +39,7 @@ for seed in range(first, first + count):
         d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
         bad.append((seed, W, H, depth, len(d), d[0].tolist()))
         print("MISMATCH", bad[-1], flush=True)
+    if (seed - first) % 250 == 249:                  # a sign of life (a silent GPU job is taken for hung)
+        print(f"... {seed - first + 1} scenes, {len(bad)} mismatching, {time.time() - t0:.0f} s", flush=True)
 print(f"{count} scenes from seed {first}: {len(bad)} mismatching, {time.time() - t0:.1f} s", flush=True)
 sys.exit(1 if bad else 0)

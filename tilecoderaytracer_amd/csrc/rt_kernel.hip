@@ -58,10 +58,34 @@ __device__ __forceinline__ float dot3(const V3 a, const V3 b) { return a.x * b.x
 __device__ __forceinline__ V3 sub3(const V3 a, const V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 add3(const V3 a, const V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ V3 scale3(const V3 v, const float f) { return mk(v.x * f, v.y * f, v.z * f); }
-/* vector3d::normalize, src/vector3d.h:55-73: sqrtf then three true divides */
+/* n / l from r = the refined reciprocal of l: the tail of the compiler's own expansion of a correctly rounded divide
+ * (normalize3() below says when it may be used) */
+__device__ __forceinline__ float quotient_by_refined_reciprocal(const float n, const float l, const float r) {
+    const float q0 = n * r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-l, q0, n), r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-l, q1, n), r, q1);
+}
+
+/* vector3d::normalize, src/vector3d.h:55-73: sqrtf then three true (correctly rounded) divides by the same length.
+ *
+ * The compiler expands every IEEE divide n / l into v_div_scale (x2), v_rcp, two fma that refine the reciprocal,
+ * q0 = n r, two residual/correction fma pairs (the last as v_div_fmas) and v_div_fixup: twelve instructions, thirty-six
+ * per normalisation -- a quarter of them, the refined reciprocal of l, three times over.  When no scaling is needed the
+ * scale and fixup steps are the identity (v_div_scale leaves its operand alone unless an operand is zero or denormal,
+ * the exponents differ by 96 or more, the quotient or 1/l would be denormal, or |n| < 2^-103; v_div_fixup passes the
+ * quotient through unless an operand is zero, infinite or NaN), so the SAME fma sequence with the reciprocal refined
+ * once gives the same bits: eighteen instructions.  The guard -- 2^-60 <= every |component| and the length <= 2^60, in
+ * every active lane -- puts all of those cases out of reach (|n| <= l, so the quotient is in [2^-120, 1]); a wavefront
+ * with a lane outside it (a zero component: rays along an axis) takes the plain divides. */
 __device__ __forceinline__ V3 normalize3(const V3 v) {
     const float length = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-    return mk(v.x / length, v.y / length, v.z / length);
+    const float smallest = fminf(fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+    const bool plain = !(smallest >= 0x1p-60f) || !(length <= 0x1p+60f);       /* a NaN anywhere: plain */
+    if (__builtin_amdgcn_ballot_w64(plain) != 0ull) return mk(v.x / length, v.y / length, v.z / length);
+    const float r0 = __builtin_amdgcn_rcpf(length);
+    const float r = __builtin_fmaf(__builtin_fmaf(-length, r0, 1.0f), r0, r0);
+    return mk(quotient_by_refined_reciprocal(v.x, length, r), quotient_by_refined_reciprocal(v.y, length, r),
+              quotient_by_refined_reciprocal(v.z, length, r));
 }
 
 /* vector3d::normalize of a vector that is usually already of unit length (the
