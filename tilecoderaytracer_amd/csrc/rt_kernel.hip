@@ -58,6 +58,20 @@ __device__ __forceinline__ float dot3(const V3 a, const V3 b) { return a.x * b.x
 __device__ __forceinline__ V3 sub3(const V3 a, const V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 add3(const V3 a, const V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ V3 scale3(const V3 v, const float f) { return mk(v.x * f, v.y * f, v.z * f); }
+/* sqrtf(x) for 2^-96 <= x <= 2^120 (and for a NaN or negative x, whose result -- NaN -- nobody uses): the compiler's own
+ * expansion of the correctly rounded square root -- v_sqrt_f32 (1 ulp), then the two neighbours tried with an exact fma
+ * residual each -- without the steps that scale a tiny x up and the result back down and pass 0 and infinity through
+ * (seven of its sixteen instructions).  Same instructions on the same operands as sqrtf() in that range, hence the same bits. */
+__device__ __forceinline__ float sqrt_in_range(const float x) {
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float below = __int_as_float(__float_as_int(s0) - 1), above = __int_as_float(__float_as_int(s0) + 1);
+    const float r_below = __builtin_fmaf(-below, s0, x);
+    const float r_above = __builtin_fmaf(-above, s0, x);
+    const float s1 = (0.0f >= r_below) ? below : s0;
+    return (0.0f < r_above) ? above : s1;
+}
+__device__ __forceinline__ bool sqrt_range_ok(const float x) { return (x >= 0x1p-96f) && (x <= 0x1p+120f); }
+
 /* n / l from r = the refined reciprocal of l: the tail of the compiler's own expansion of a correctly rounded divide
  * (normalize3() below says when it may be used) */
 __device__ __forceinline__ float quotient_by_refined_reciprocal(const float n, const float l, const float r) {
@@ -74,14 +88,23 @@ __device__ __forceinline__ float quotient_by_refined_reciprocal(const float n, c
  * scale and fixup steps are the identity (v_div_scale leaves its operand alone unless an operand is zero or denormal,
  * the exponents differ by 96 or more, the quotient or 1/l would be denormal, or |n| < 2^-103; v_div_fixup passes the
  * quotient through unless an operand is zero, infinite or NaN), so the SAME fma sequence with the reciprocal refined
- * once gives the same bits: eighteen instructions.  The guard -- 2^-60 <= every |component| and the length <= 2^60, in
- * every active lane -- puts all of those cases out of reach (|n| <= l, so the quotient is in [2^-120, 1]); a wavefront
- * with a lane outside it (a zero component: rays along an axis) takes the plain divides. */
-__device__ __forceinline__ V3 normalize3(const V3 v) {
-    const float length = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+ * once gives the same bits: eighteen instructions.  The guard -- 2^-60 <= every |component| and 2^-96 <= the squared
+ * length <= 2^120, in every active lane -- puts all of those cases out of reach (|n| <= l, so the quotient is in
+ * [2^-120, 1]) and lets the square root take its short form too (sqrt_in_range()); a wavefront with a lane outside it (a
+ * zero component: rays along an axis) takes the plain square root and divides.  *length_out = the length, which callers
+ * that need it (the distance to the light) would otherwise compute a second time. */
+__device__ __forceinline__ V3 normalize3(const V3 v, float *length_out = nullptr) {
+    const float squared = v.x * v.x + v.y * v.y + v.z * v.z;
     const float smallest = fminf(fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
-    const bool plain = !(smallest >= 0x1p-60f) || !(length <= 0x1p+60f);       /* a NaN anywhere: plain */
-    if (__builtin_amdgcn_ballot_w64(plain) != 0ull) return mk(v.x / length, v.y / length, v.z / length);
+    /* in range for the short square root and the short divides (then the length is in [2^-48, 2^60]); a NaN anywhere: plain */
+    const bool plain = !(smallest >= 0x1p-60f) || !sqrt_range_ok(squared);
+    if (__builtin_amdgcn_ballot_w64(plain) != 0ull) {
+        const float length = sqrtf(squared);
+        if (length_out) *length_out = length;
+        return mk(v.x / length, v.y / length, v.z / length);
+    }
+    const float length = sqrt_in_range(squared);
+    if (length_out) *length_out = length;
     const float r0 = __builtin_amdgcn_rcpf(length);
     const float r = __builtin_fmaf(__builtin_fmaf(-length, r0, 1.0f), r0, r0);
     return mk(quotient_by_refined_reciprocal(v.x, length, r), quotient_by_refined_reciprocal(v.y, length, r),
@@ -193,7 +216,8 @@ __device__ __forceinline__ void sphere_distance(const float4 s, const V3 o, cons
     *hit = false;
     *dist = 0.0f;
     if (wave_any(candidate)) {
-        const float sq = sqrtf(d_squared);
+        /* candidates have d_squared >= 1e-9: in the short square root's range unless it is huge */
+        const float sq = wave_any(candidate && !(d_squared <= 0x1p+120f)) ? sqrtf(d_squared) : sqrt_in_range(d_squared);
         const float root1 = v - sq;
         const float root2 = v + sq;
         /* the root2 > 0 / root1 < 0 / "< 65535" ladder of :93-116 */
@@ -225,7 +249,12 @@ __device__ __forceinline__ bool four_spheres_block(const float4 s0, const float4
     const bool c2 = k2 && !(v2 < (float)0) && !(q2 < (float)1E-9), c3 = k3 && !(v3 < (float)0) && !(q3 < (float)1E-9);
     bool any = false;
     if (wave_any(c0 || c1 || c2 || c3)) {
-        const float r0 = sqrtf(q0), r1 = sqrtf(q1), r2 = sqrtf(q2), r3 = sqrtf(q3);
+        float r0, r1, r2, r3;
+        if (wave_any((c0 && !(q0 <= 0x1p+120f)) || (c1 && !(q1 <= 0x1p+120f)) || (c2 && !(q2 <= 0x1p+120f)) || (c3 && !(q3 <= 0x1p+120f)))) {
+            r0 = sqrtf(q0); r1 = sqrtf(q1); r2 = sqrtf(q2); r3 = sqrtf(q3);
+        } else {                                              /* candidates have q >= 1e-9: the short square root's range */
+            r0 = sqrt_in_range(q0); r1 = sqrt_in_range(q1); r2 = sqrt_in_range(q2); r3 = sqrt_in_range(q3);
+        }
         const float a0 = v0 - r0, b0 = v0 + r0, a1 = v1 - r1, b1 = v1 + r1, a2 = v2 - r2, b2 = v2 + r2, a3 = v3 - r3, b3 = v3 + r3;
         const bool h0 = c0 && (b0 > (float)0) && ((a0 < (float)0) ? (b0 < 65535.0f) : (a0 < 65535.0f)) && a0 < dist_to_light;
         const bool h1 = c1 && (b1 > (float)0) && ((a1 < (float)0) ? (b1 < 65535.0f) : (a1 < 65535.0f)) && a1 < dist_to_light;
@@ -1537,8 +1566,8 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
                 /* inShade, :743-771 */
                 const V3 dir = sub3(xyz(l0), P);
-                const float dist_to_light = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
-                const V3 light_ray = normalize3(dir);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
+                float dist_to_light;                         /* |dir|, :748 -- the length normalize3() takes the root of anyway */
+                const V3 light_ray = normalize3(dir, &dist_to_light);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
                 bool blocked;
                 if constexpr (kMode == 6) blocked = in_shade_fast<kStats>(p, lds, ctl_words, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
