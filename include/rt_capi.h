@@ -255,6 +255,9 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   (rt_get_timeline); the product library accepts 0 only
  *   "fast"          scenes without clustered runs: 1 (default) = one kind-sorted item list
  *                   with direct test records (FAST tables), 0 = the two item tables
+ *   "primary"       FAST tables: 1 (default) = the scan of the camera rays culls by the pixel rectangle
+ *                   every item's box projects to (computed per launch from the camera; scenes of up to
+ *                   64 items), 0 = by the bundle of rays like every other scan
  *   "tight_planes"  0 = plane items get the (much larger) padding of sphere items
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
  *   "cluster_leaf"  spheres per leaf of a clustered run (default 16; 0 = no clustering) */

@@ -177,6 +177,40 @@ def test_axis_aligned_rooms(oracle, seed):
         assert_same(r.render(88, 72, 5), want, f"room seed {seed}, item tables")
 
 
+@pytest.mark.parametrize("tile_z", [0, 1, 4, 64])
+def test_primary_table_against_the_bundle_cull(oracle, tile_z):
+    """FAST tables: the camera rays' scan culls by the items' projected pixel rectangles (option primary = 1, the default) or
+    by the bundle like every other scan (0): same image, for whole frames and strips, the reference's two cameras, a rolled one,
+    and an eye that sits inside a sphere (that item gets the whole image)."""
+    from scene_gen import build_room
+    cases = [(HostScene.builtin(), oracle.OracleScene.builtin(), 150, 120, 4)]
+    cases.append((build_room(HostScene.empty(), 206), build_room(oracle.OracleScene(), 206), 97, 61, 5))
+    host, orc = build_room(HostScene.empty(), 210), build_room(oracle.OracleScene(), 210)
+    for sc in (host, orc):
+        i = sc.add_sphere((0.0, -1.0, 2.5), 3.0)          # around the eye of the two-mirrors camera
+        sc.set_reflective(i, 0.5)
+    cases.append((host, orc, 64, 80, 4))
+    host, orc = build_room(HostScene.empty(), 211), build_room(oracle.OracleScene(), 211)
+    hc = host.camera.contents
+    h = np.array(list(hc.vector_horizontal), dtype=np.float32); v = np.array(list(hc.vector_vertical), dtype=np.float32)
+    ca, sa = np.float32(np.cos(0.4)), np.float32(np.sin(0.4))
+    h2, v2 = ca * h + sa * v, ca * v - sa * h
+    for k in range(3):
+        hc.vector_horizontal[k], hc.vector_vertical[k] = float(h2[k]), float(v2[k])
+    orc.cam.vector_horizontal = type(orc.cam.vector_horizontal)(*[float(c) for c in h2])
+    orc.cam.vector_vertical = type(orc.cam.vector_vertical)(*[float(c) for c in v2])
+    cases.append((host, orc, 90, 70, 4))
+    for host, orc, W, H, depth in cases:
+        want = orc.render(W, H, depth)
+        r = Renderer(host)
+        if tile_z:
+            r.set_option("tile_z", tile_z)
+        for primary in (1, 0):
+            r.set_option("primary", primary)
+            assert_same(r.render(W, H, depth), want, f"primary {primary}, tile_z {tile_z}")
+            assert_same(r.render(W, H, depth, 13, W - 7), want[13:W - 7], f"primary {primary}, tile_z {tile_z}, strip")
+
+
 def test_partial_shadow_range(oracle):
     """Scene::SetObjectIndices(rank, size) narrows the shadow scan (src/Scene.cpp:486-504)."""
     from scene_gen import build_random

@@ -93,6 +93,7 @@ struct rt_scene {
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
     int aa_planes = 1;            /* class-sorted fast path for axis-aligned finite planes             */
+    int primary_opt = 1;          /* FAST tables: the camera rays' scan culls by projected pixel rectangles (PRIMARY table); 0: the bundle cull */
     int fast_opt = 1;             /* scenes without clustered runs: the kind-sorted item list with direct records (FAST tables); 0: the two item tables */
     int tight_planes = 1;         /* plane items: boxes padded for a plane's rounding only (RT_ITEM_TIGHT); 0: the sphere padding */
     int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
@@ -678,16 +679,154 @@ int horizon_start(const rt_scene *s, const rt_camera_desc *cam) {
     return std::max(0, (int)(dz * 1000.0) - 8);
 }
 
+/* PRIMARY table (rt_tables.h): for every item of the FAST list, the rectangle of pixels of a W x H image whose camera ray can
+ * reach the item, and a lower bound of the distance at which it does.
+ *
+ * Exactness.  The kernel's culls rest on: a hit the reference's float test reports lies inside the item's box grown by the
+ * slack of RT_CULL_SLACK (rt_kernel.hip; the box is already padded on the host).  The camera ray of pixel (x, z) leaves the eye
+ * through the screen point so + ch a + cv b with a = x/W sw - shw, b = z/H sh - shh (src/Camera.cpp:71-84), evaluated in floats:
+ * off the exact point by a few ulp of the coordinates involved.  So the hit is on a line from the eye through a point within
+ * `err` of that pixel's exact screen point, and inside the grown box.  The grown box is convex and -- when all eight corners are
+ * in front of the eye -- its central projection onto the screen plane is the hull of the projected corners: their bounding
+ * rectangle in (a, b), turned into pixels and widened by two pixels plus `err` in pixels, contains every pixel that can hit the
+ * item.  A box that reaches behind the camera is clipped a little in front of the eye first (see below: nothing a ray can reach is
+ * lost), an unbounded one is cut 70 000 away (the rays end at 65 535), one entirely behind the camera gets no pixel, and an item
+ * with the eye inside its grown box gets the whole image.  The entry distance is the Euclidean distance from the eye to the grown box less the scans' tolerance (a ray's
+ * parameter is its distance: |d| = 1 to 2e-7); 0 for items that contain the eye, which are always tested.
+ * Returns false when no table can be made (too many items, a degenerate camera, an image too large for 16-bit pixels). */
+bool primary_table(const rt_scene *s, const rt_camera_desc *cam, int W, int H, uint32_t *out /* [n][4] */) {
+    const int n = s->base.n_fast_items;
+    if (n <= 0 || n > RT_PRIMARY_ITEMS || W > 30000 || H > 30000) return false;
+    double eye[3], w0[3], ch[3], cv[3];
+    for (int k = 0; k < 3; ++k) {
+        eye[k] = cam->eye_origin[k]; w0[k] = (double)cam->screen_origin[k] - eye[k];
+        ch[k] = cam->vector_horizontal[k]; cv[k] = cam->vector_vertical[k];
+    }
+    const double sw = cam->screen_width, sh = cam->screen_height, shw = cam->screen_halfwidth, shh = cam->screen_halfheight;
+    if (!(sw > 0.0) || !(sh > 0.0) || !std::isfinite(sw) || !std::isfinite(sh) || !std::isfinite(shw) || !std::isfinite(shh)) return false;
+    /* M = [w0 | ch | cv]; c - eye = u0 (w0 + a ch + b cv) with a = u1/u0, b = u2/u0 */
+    const double m[3][3] = {{w0[0], ch[0], cv[0]}, {w0[1], ch[1], cv[1]}, {w0[2], ch[2], cv[2]}};
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    double scale = 0.0;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) scale = std::max(scale, std::fabs(m[r][c]));
+    if (!std::isfinite(det) || !(std::fabs(det) > 1e-9 * scale * scale * scale) || scale == 0.0) return false;
+    double inv[3][3];
+    inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det; inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+    inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det; inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+    inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det; inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    /* float error of a pixel's screen point (a few ulp of every term's magnitude), in units of a and b, in pixels */
+    double mag = 0.0, len_h = 0.0, len_v = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        mag += std::fabs((double)cam->screen_origin[k]) + std::fabs(eye[k]) + std::fabs(ch[k]) * (std::fabs(shw) + sw) + std::fabs(cv[k]) * (std::fabs(shh) + sh);
+        len_h += ch[k] * ch[k]; len_v += cv[k] * cv[k];
+    }
+    len_h = std::sqrt(len_h); len_v = std::sqrt(len_v);
+    if (!(len_h > 0.0) || !(len_v > 0.0)) return false;
+    const double err = 16.0 * 1.2e-7 * mag;                       /* 16 roundings' worth */
+    const double margin_x = 2.0 + std::ceil(err / len_h * (double)W / sw), margin_z = 2.0 + std::ceil(err / len_v * (double)H / sh);
+    if (!(margin_x < 1000.0) || !(margin_z < 1000.0)) return false;
+    const Quad *boxes = s->image.data() + s->base.fast_box_off;
+    for (int i = 0; i < n; ++i) {
+        const Quad &b0 = boxes[2 * i], &b1 = boxes[2 * i + 1];
+        uint32_t bits; std::memcpy(&bits, &b0.v[3], 4);
+        /* an axis the item is unbounded on (infinite planes): the rays end at 65535 (the reference's infinity), so 70 000 either
+         * side of the eye is as good as unbounded */
+        double lo[3], hi[3], far[3], far_sum = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::isfinite((double)b0.v[k]) ? (double)b0.v[k] : eye[k] - 7.0e4;
+            hi[k] = std::isfinite((double)b1.v[k]) ? (double)b1.v[k] : eye[k] + 7.0e4;
+            lo[k] = std::max(lo[k], eye[k] - 7.0e4); hi[k] = std::min(hi[k], eye[k] + 7.0e4);
+            far[k] = std::max(std::fabs(lo[k] - eye[k]), std::fabs(hi[k] - eye[k]));
+            far_sum += far[k];
+        }
+        int x_lo = -32768, x_hi = 32767, z_lo = -32768, z_hi = 32767;         /* the whole image, always tested: the fallback */
+        float entry = 0.0f;
+        {
+            /* the kernel's slack (RT_CULL_SLACK: 1.5e-3 of the L1 distance for sphere-like items, 1e-5 per axis for planes), twice over */
+            double d2 = 0.0;
+            bool eye_inside = true;
+            for (int k = 0; k < 3; ++k) {
+                const double ex = 2.0 * (((bits & RT_ITEM_TIGHT) ? 1.0e-5 * far[k] : 1.5e-3 * far_sum) + 1.0e-4);
+                lo[k] -= ex; hi[k] += ex;
+                const double dk = std::max(std::max(lo[k] - eye[k], eye[k] - hi[k]), 0.0);
+                if (dk > 0.0) eye_inside = false;
+                d2 += dk * dk;
+            }
+            const double dist = std::sqrt(d2);
+            if (!eye_inside && dist > 0.0 && lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+                /* In the camera's coordinates u (c - eye = u0 w0 + u1 ch + u2 cv) a ray of pixel (a, b) is u = lambda (1, a, b):
+                 * what it can reach of the box has u0 = lambda > 0.  The part of the box with u0 < eps lies within
+                 * eps (|w0| + |a ch| + |b cv|) of the eye for the image's pixels (|a|, |b| <= the screen's half sizes + 1); with
+                 * eps below dist / that length it is empty of reachable points, so the box may be clipped at u0 = eps before it
+                 * is projected -- which keeps the projection finite for boxes that reach behind the camera. */
+                double reach = 0.0;
+                for (int k = 0; k < 3; ++k) reach += std::fabs(w0[k]) + std::fabs(ch[k]) * (std::fabs(shw) + sw + 1.0) + std::fabs(cv[k]) * (std::fabs(shh) + sh + 1.0);
+                const double eps = std::min(0.5, 0.5 * dist / reach);
+                double u[8][3];
+                for (int c = 0; c < 8; ++c) {
+                    const double v[3] = {((c & 1) ? hi[0] : lo[0]) - eye[0], ((c & 2) ? hi[1] : lo[1]) - eye[1], ((c & 4) ? hi[2] : lo[2]) - eye[2]};
+                    for (int r = 0; r < 3; ++r) u[c][r] = inv[r][0] * v[0] + inv[r][1] * v[1] + inv[r][2] * v[2];
+                }
+                double a_lo = 1e300, a_hi = -1e300, b_lo = 1e300, b_hi = -1e300;
+                int kept = 0;
+                auto project = [&](double u0, double u1, double u2) {
+                    a_lo = std::min(a_lo, u1 / u0); a_hi = std::max(a_hi, u1 / u0);
+                    b_lo = std::min(b_lo, u2 / u0); b_hi = std::max(b_hi, u2 / u0);
+                    ++kept;
+                };
+                for (int c = 0; c < 8; ++c) {
+                    if (u[c][0] >= eps) project(u[c][0], u[c][1], u[c][2]);
+                    for (int axis = 0; axis < 3; ++axis) {                      /* the edges from c towards higher corners */
+                        const int o2 = c | (1 << axis);
+                        if (o2 == c) continue;
+                        const double p0 = u[c][0], p1 = u[o2][0];
+                        if ((p0 < eps) != (p1 < eps)) {                         /* the edge crosses u0 = eps */
+                            const double f = (eps - p0) / (p1 - p0);
+                            project(eps, u[c][1] + f * (u[o2][1] - u[c][1]), u[c][2] + f * (u[o2][2] - u[c][2]));
+                        }
+                    }
+                }
+                const double e = dist - 1.0e-4 * dist - 1.0e-6;
+                entry = e > 0.0 ? std::nextafter((float)e, 0.0f) : 0.0f;              /* rounded towards 0 */
+                if (!(entry > 0.0f) || !std::isfinite(entry)) entry = 0.0f;
+                if (kept == 0) {
+                    x_lo = 1; x_hi = 0; z_lo = 1; z_hi = 0;                            /* all of it behind the camera: no pixel */
+                } else if (std::isfinite(a_lo) && std::isfinite(a_hi) && std::isfinite(b_lo) && std::isfinite(b_hi)) {
+                    auto clamp16 = [](double v) { return (int)std::max(-32768.0, std::min(32767.0, v)); };
+                    /* (a relative widening for the interpolated points and the division) */
+                    const double wa = 1e-9 * (std::fabs(a_lo) + std::fabs(a_hi)), wb = 1e-9 * (std::fabs(b_lo) + std::fabs(b_hi));
+                    x_lo = clamp16(std::floor((a_lo - wa + shw) / sw * (double)W - margin_x));
+                    x_hi = clamp16(std::ceil((a_hi + wa + shw) / sw * (double)W + margin_x));
+                    z_lo = clamp16(std::floor((b_lo - wb + shh) / sh * (double)H - margin_z));
+                    z_hi = clamp16(std::ceil((b_hi + wb + shh) / sh * (double)H + margin_z));
+                }
+            }
+        }
+        uint32_t ebits; std::memcpy(&ebits, &entry, 4);
+        out[4 * i + 0] = ((uint32_t)x_lo & 0xFFFFu) | ((uint32_t)x_hi << 16);
+        out[4 * i + 1] = ((uint32_t)z_lo & 0xFFFFu) | ((uint32_t)z_hi << 16);
+        out[4 * i + 2] = ebits;
+        out[4 * i + 3] = 0u;
+    }
+    return true;
+}
+
 /* Workgroup size and where the bounce stack goes.  The stack is 16 B per level
  * per thread.  As many of its lowest levels as fit share LDS with the scene
  * tables while RT_STACK_LDS_SHARE workgroups per CU still fit in the 160 KiB
  * (nearly every reflection chain uses the first levels, few the deep ones); the
  * rest lives in HBM.  Option "stack": 1 = all of it in LDS, 2 = all in HBM. */
+int primary_quads(const rt_scene *s) {
+    return (s->primary_opt && s->base.n_fast_items > 0 && s->base.n_fast_items <= RT_PRIMARY_ITEMS) ? s->base.n_fast_items : 0;
+}
+
 int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, int *lds_bytes, int *stack_lds_levels, bool *global_tables) {
     /* Tables in LDS (staged once per workgroup), or -- large scenes -- left in global memory and read
      * through the L2 (rt_render_kernel_large): automatic beyond RT_LDS_TABLE_BYTES, where LDS would hold
      * fewer than two workgroups per CU; beyond 160 KiB it is the only way.  Option "tables". */
-    size_t scene_bytes = (size_t)s->base.image_quads * 16;
+    /* (FAST tables carry this launch's PRIMARY table behind the image: one quad per item) */
+    size_t scene_bytes = ((size_t)s->base.image_quads + (primary_quads(s) > 0 ? (size_t)primary_quads(s) : 0)) * 16;
     /* the counting build has no global-memory variant: automatic means LDS for it whenever the tables fit at all */
     *global_tables = s->tables_opt == 2 ||
                      (s->tables_opt == 0 && scene_bytes > (counting ? (size_t)RT_MAX_LDS_BYTES : (size_t)RT_LDS_TABLE_BYTES));
@@ -756,7 +895,11 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.W = W; p.H = H; p.x0 = x0; p.x1 = x1; p.max_depth = max_depth;
     p.stack_lds_levels = stack_lds_levels;
     p.stack_stride = block;
-    p.stack_off = global_tables ? 0 : s->base.image_quads;
+    p.n_primary = 0;
+    p.primary_off = s->base.image_quads;
+    if (!global_tables && primary_quads(s) > 0 && primary_table(s, cam, W, H, p.primary)) p.n_primary = primary_quads(s);
+    /* (the LDS place of the table is reserved whether or not this camera admits one) */
+    p.stack_off = global_tables ? 0 : s->base.image_quads + primary_quads(s);
     p.cull = s->cull_opt;
     /* Wavefront tile shape (speed only).  4 x 16 (x by z) makes every lane-row's
      * stores whole 64-byte sectors (16 pixels x 12 B = 192 B, aligned): measured
@@ -793,7 +936,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
 
     s->launch.block_threads = block;
     s->launch.lds_bytes = lds_bytes;
-    s->launch.scene_lds_bytes = global_tables ? 0 : s->base.image_quads * 16;
+    s->launch.scene_lds_bytes = global_tables ? 0 : (s->base.image_quads + primary_quads(s)) * 16;
     s->launch.tile_x = tile_x;
     s->launch.tile_z = tile_z;
     s->launch.grid_blocks = 0;
@@ -1177,6 +1320,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
                           : fail(RT_ERR_INVALID, "the timeline is recorded by diagnostic builds only: make -C tilecoderaytracer_amd/csrc variant NAME=timeline DEFS=-DRT_TIMELINE=1");
 #endif
     }
+    if (!std::strcmp(key, "primary")) { s->primary_opt = value != 0; return RT_OK; }
     if (!std::strcmp(key, "heavy")) {
         if (value < -1 || value > 4096) return fail(RT_ERR_INVALID, "heavy must be -1 (automatic), 0 (off) or 1 + the band's half-width in tile rows");
         s->heavy_opt = value;

@@ -1248,7 +1248,8 @@ __device__ __forceinline__ void fast_item_distance(const RtParams &p, const floa
 template <bool kStats>
 __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4 *lds, const uint32_t *__restrict__ ctl_words,
                                                  const bool active, const V3 o, const V3 d, const bool have_origin_box,
-                                                 const V3 origins_lo, const V3 origins_hi,
+                                                 const V3 origins_lo, const V3 origins_hi, const bool camera_rays,
+                                                 const int tile_x0, const int tile_z0,
                                                  float *best_out, int *best_idx_out, Stats<kStats> &st) {
     float best = 65535.0f;
     int best_idx = -1;
@@ -1260,18 +1261,31 @@ __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4
     const float4 *recs = lds + p.fast_rec_off;
     const unsigned long long active_mask = __builtin_amdgcn_ballot_w64(active);
 
-    V3 dlo, dhi, olo = origins_lo, ohi = origins_hi;
-    wave_bounds3(d, active, &dlo, &dhi);
-    if (!have_origin_box) wave_bounds3(o, active, &olo, &ohi);      /* the eye for primary rays, else the previous level's shading points */
-    float lax, hax, lbx, hbx, lay, hay, lby, hby, laz, haz, lbz, hbz;
-    bound_multipliers(dlo.x, dhi.x, &lax, &hax, &lbx, &hbx);
-    bound_multipliers(dlo.y, dhi.y, &lay, &hay, &lby, &hby);
-    bound_multipliers(dlo.z, dhi.z, &laz, &haz, &lbz, &hbz);
+    /* The camera rays of a tile (level 0) with a PRIMARY table (rt_tables.h): the host has projected every item's box to the
+     * rectangle of pixels whose ray can reach it, with the distance it is at least away; lane i compares item i's rectangle
+     * with the tile's -- no bundle, no reciprocals, no box arithmetic.  Every other scan: the bundle cull. */
+    const bool by_pixels = camera_rays && p.n_primary > 0;
+    V3 dlo = d, dhi = d, olo = origins_lo, ohi = origins_hi;
+    float lax = 0, hax = 0, lbx = 0, hbx = 0, lay = 0, hay = 0, lby = 0, hby = 0, laz = 0, haz = 0, lbz = 0, hbz = 0;
+    if (!by_pixels) {
+        wave_bounds3(d, active, &dlo, &dhi);
+        if (!have_origin_box) wave_bounds3(o, active, &olo, &ohi);      /* the eye for primary rays, else the previous level's shading points */
+        bound_multipliers(dlo.x, dhi.x, &lax, &hax, &lbx, &hbx);
+        bound_multipliers(dlo.y, dhi.y, &lay, &hay, &lby, &hby);
+        bound_multipliers(dlo.z, dhi.z, &laz, &haz, &lbz, &hbz);
+    }
     const bool finite_rays = (__builtin_amdgcn_ballot_w64(!ray_is_finite(o, d)) & active_mask) == 0ull;
 
     for (int base = 0; base < n_items; base += 64) {
         uint32_t key;                      /* this lane's item: tolerant bundle entry distance (high bits) | lane */
-        {
+        if (by_pixels) {                   /* n_items <= 64: one round */
+            const uint4 rect = reinterpret_cast<const uint4 *>(lds)[p.primary_off + min(lane, n_items - 1)];
+            const int x_lo = (int)(short)(rect.x & 0xFFFFu), x_hi = (int)rect.x >> 16;
+            const int z_lo = (int)(short)(rect.y & 0xFFFFu), z_hi = (int)rect.y >> 16;
+            const int tile_x1 = tile_x0 + (64 >> p.tile_z_log2) - 1, tile_z1 = tile_z0 + (1 << p.tile_z_log2) - 1;
+            const bool candidate = lane < n_items && x_lo <= tile_x1 && x_hi >= tile_x0 && z_lo <= tile_z1 && z_hi >= tile_z0;
+            key = candidate ? ((rect.z & ~63u) | (uint32_t)lane) : 0xFFFFFFFFu;
+        } else {
             const int mine = min(base + lane, n_items - 1);
             const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
             float ax = b0.x - ohi.x, bx = b1.x - olo.x;
@@ -1489,7 +1503,11 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
             const int n_alive = __popcll(__builtin_amdgcn_ballot_w64(alive));
             st_wave(st, n_alive <= 16 ? ST_NEAREST_1_16 : n_alive <= 32 ? ST_NEAREST_17_32 : n_alive <= 48 ? ST_NEAREST_33_48 : ST_NEAREST_49_64);
         }
-        if constexpr (kMode == 6) nearest_hit_fast<kStats>(p, lds, ctl_words, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);
+        if constexpr (kMode == 6) {
+            const int tzl_n = here(p.tile_z_log2);
+            nearest_hit_fast<kStats>(p, lds, ctl_words, alive, o, d, have_box, box_lo, box_hi, level == 0,
+                                     p.x0 + here(tile_col) * (64 >> tzl_n), here(tile_row) << tzl_n, &t, &idx, st);
+        }
         else nearest_hit_items<kStats, kMode>(p, lds, wlds, alive, o, d, have_box, box_lo, box_hi, &t, &idx, st);   /* whole wavefront, converged */
         st_cycles(st, ST_CYCLES_NEAREST, t_scan);
         const unsigned long long t_winner = st_clock<kStats>();
@@ -1710,6 +1728,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     }
     if constexpr (!kGlobalTables) {
         for (int q = threadIdx.x; q < p.image_quads; q += blockDim.x) wlds[q] = image[q];
+        if constexpr (kFast) {               /* this launch's PRIMARY table comes with the kernel arguments */
+            if ((int)threadIdx.x < p.n_primary) wlds[p.primary_off + threadIdx.x] = reinterpret_cast<const float4 *>(p.primary)[threadIdx.x];
+        }
         __syncthreads();
     }
 

@@ -117,6 +117,8 @@ enum { RT_DESK_STATE = 0, RT_DESK_CURSOR, RT_DESK_INSIDE, RT_DESK_FINISHED, RT_D
 
 #define RT_STACK_ENTRY_BYTES 16   /* {local.rgb, bits(object index | texsel << 16)} per bounce level per lane */
 
+#define RT_PRIMARY_ITEMS 64          /* scenes with more FAST items than this have no PRIMARY table */
+
 typedef struct RtParams {
     /* camera (src/Camera.cpp:71-84) */
     float so[3], ch[3], cv[3], eye[3];
@@ -155,6 +157,14 @@ typedef struct RtParams {
     int32_t n_fast_items, n_fast_shadow; /* items in all; the first n_fast_shadow are the shadow scan's */
     int32_t fast_box_off, fast_rec_off;  /* quad offsets: 2 box quads and 2 record quads per item */
     int32_t fast_ctl_off;                /* u32 offset (4 per quad): one control word per item */
+    /* PRIMARY table (FAST tables, at most RT_PRIMARY_ITEMS items; rt_capi.hip: primary_table()): per item of the FAST list, for
+     * THIS launch's camera and image, the rectangle of pixels whose camera ray can reach the item's box and a lower bound of the
+     * distance at which it does: the nearest-hit scan of the camera rays needs no bundle bounds, no reciprocals and no box
+     * arithmetic -- a tile is a pixel rectangle.  n_primary = items (0: no table, the camera rays take the general cull);
+     * primary_off = its place in LDS (quads, behind the image; one quad per item: {x_lo | x_hi << 16 (int16 pixels),
+     * z_lo | z_hi << 16, bits of the entry distance, 0}). */
+    int32_t n_primary, primary_off;
+    uint32_t primary[RT_PRIMARY_ITEMS * 4];
     /* one word of host memory the kernel can write (rt_scene's sticky device error): set when a HELP wait timed out */
     uint64_t error_word;
     /* diagnostic (option "timeline"): 0, or device memory for RT_TIMELINE_WORDS u64 per wavefront tile, row-major:
