@@ -98,17 +98,20 @@ __device__ __forceinline__ V3 normalize3(const V3 v, float *length_out = nullptr
     const float smallest = fminf(fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
     /* in range for the short square root and the short divides (then the length is in [2^-48, 2^60]); a NaN anywhere: plain */
     const bool plain = !(smallest >= 0x1p-60f) || !sqrt_range_ok(squared);
+    float length, x, y, z;
     if (__builtin_amdgcn_ballot_w64(plain) != 0ull) {
-        const float length = sqrtf(squared);
-        if (length_out) *length_out = length;
-        return mk(v.x / length, v.y / length, v.z / length);
+        length = sqrtf(squared);
+        x = v.x / length; y = v.y / length; z = v.z / length;
+    } else {
+        length = sqrt_in_range(squared);
+        const float r0 = __builtin_amdgcn_rcpf(length);
+        const float r = __builtin_fmaf(__builtin_fmaf(-length, r0, 1.0f), r0, r0);
+        x = quotient_by_refined_reciprocal(v.x, length, r);
+        y = quotient_by_refined_reciprocal(v.y, length, r);
+        z = quotient_by_refined_reciprocal(v.z, length, r);
     }
-    const float length = sqrt_in_range(squared);
     if (length_out) *length_out = length;
-    const float r0 = __builtin_amdgcn_rcpf(length);
-    const float r = __builtin_fmaf(__builtin_fmaf(-length, r0, 1.0f), r0, r0);
-    return mk(quotient_by_refined_reciprocal(v.x, length, r), quotient_by_refined_reciprocal(v.y, length, r),
-              quotient_by_refined_reciprocal(v.z, length, r));
+    return mk(x, y, z);
 }
 
 /* vector3d::normalize of a vector that is usually already of unit length (the
@@ -955,6 +958,9 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
 #ifndef RT_PAIR_DIRECT_LANES
 #define RT_PAIR_DIRECT_LANES 32
 #endif
+#ifndef RT_NT_STORES
+#define RT_NT_STORES 1           /* the image leaves through streaming stores (HBM bytes per built-in frame 272 -> 241 MB) */
+#endif
 #ifndef RT_LEAVES_ABREAST
 #define RT_LEAVES_ABREAST 1           /* shadow scans: the box tests of two consecutive candidate leaves side by side (grid-32 5.14 -> 4.99 ms) */
 #endif
@@ -1082,7 +1088,10 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                         float4 *rays = help_rays + (size_t)blockIdx.x * 128;
                         rays[lane] = make_float4(o.x, o.y, o.z, dist_to_light);
                         rays[64 + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(blocked ? RT_COOP_IDLE : 1u));
-                        __threadfence();
+                        /* the helpers are wavefronts of this workgroup, on this CU and behind the same vector L1: workgroup
+                         * scope orders the rays before the OPEN below at the cost of a wait (an agent-scope fence writes the
+                         * XCD's L2 back and invalidates it, once per opened desk) */
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {
                             desk_write(desk, RT_DESK_CURSOR, 0u);
                             desk_write(desk, RT_DESK_MASK_LO, (uint32_t)leaf_mask);
@@ -1678,7 +1687,12 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
         const int sx = here(tile_col) * (64 >> tzl_b) + (lane >> tzl_b);   /* x - x0 */
         const int sz = (here(tile_row) << tzl_b) + (lane & ((1 << tzl_b) - 1));
         float *dst = out + ((size_t)sx * (size_t)p.H + (size_t)sz) * 3;
+#if RT_NT_STORES
+        /* written once, never read here: streaming stores leave the L2 to the bounce stack and the scratch lines */
+        __builtin_nontemporal_store(C.x, dst); __builtin_nontemporal_store(C.y, dst + 1); __builtin_nontemporal_store(C.z, dst + 2);
+#else
         dst[0] = C.x; dst[1] = C.y; dst[2] = C.z;
+#endif
     }
     if constexpr (kStats) {
         st_cycles(st, ST_CYCLES_TILE, t_start);
