@@ -247,6 +247,10 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   third of the image's width (one GPU's share on three or more), a band of
  *                   0.25 % of the image height either side of the line; 0 = off; k = always,
  *                   k - 1 tile rows either side
+ *   "tile_prio"     a wavefront's priority on its SIMD follows the bounce level of its tile (the
+ *                   tiles whose rays go on bouncing are the long ones, and a launch short of tiles
+ *                   waits for them): -1 (default) = automatic, for strips of at most a third of
+ *                   the image's width; 0 = off; 1 = on
  *   "help_spin_limit" the bound of an owner's wait for helpers to leave its desk (default
  *                   2^22 polls); -1 makes every such wait count as timed out: the owner then
  *                   tests the leaves itself (same pixels), its workgroup stops helping, and

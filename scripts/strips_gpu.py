@@ -6,10 +6,12 @@ from tilecoderaytracer_amd import HostScene, Renderer
 from tilecoderaytracer_amd.distributed import strip_bounds
 import torch
 S = 4096
+NS = tuple(int(a[2:]) for a in sys.argv[1:] if a.startswith("N=")) or (2, 4, 8)      # N=8 cut=0: equal strips of 8 only
+CUT = "cut=0" not in sys.argv[1:]
 for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8), ("grid32-noshadow", 4)]:
     r = Renderer(HostScene.named(name))
     for a in sys.argv[1:]:
-        if "=" in a:
+        if "=" in a and not a.startswith(("N=", "cut=")):
             r.set_option(a.split("=")[0], int(a.split("=")[1]))
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream().cuda_stream
@@ -22,10 +24,12 @@ for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8), ("grid32-noshadow"
         tm = r.timing()
         return tm.sum_kernel_ms / tm.launches
     full = t(0, S)
-    for N in (2, 4, 8):
+    for N in NS:
         ts = [t(*strip_bounds(S, N, k)[:2]) for k in range(N)]
         print(f"{name:8s} N={N}: full {full:.3f} ms; strips " + " ".join(f"{x:.3f}" for x in ts) +
-              f"; max {max(ts):.3f} -> render-bound speedup {full / max(ts):.2f}x", flush=True)
+              f"; max {max(ts):.3f} sum {sum(ts):.3f} -> render-bound speedup {full / max(ts):.2f}x", flush=True)
+        if not CUT:
+            continue
         # what bench.py does at N > 1: re-cut the strips by the measured cost (balanced_bounds, nothing to send in this
         # render-only model), twice; boundaries on multiples of 16 columns
         import numpy as np

@@ -803,6 +803,20 @@ def test_heavy_tiles_do_not_change_results(oracle, name, W, H, depth, x0, x1, he
         assert_same(r.render(W, H, depth, x0, x1), want[x0:x1], f"{name} heavy {heavy}")
 
 
+@pytest.mark.parametrize("name,W,H,depth", [("builtin", 70, 90, 6), ("grid16", 96, 64, 8), ("twomirrors", 64, 64, 12)])
+def test_tile_priority_does_not_change_results(oracle, name, W, H, depth):
+    """rt_set_option("tile_prio", k): wavefronts raise their priority with their tile's bounce level (scheduling only)."""
+    from tilecoderaytracer_amd import RtError
+    want = oracle.OracleScene.named(name).render(W, H, depth)
+    r = Renderer(HostScene.named(name))
+    for prio in (1, 0, -1):
+        r.set_option("tile_prio", prio)
+        assert_same(r.render(W, H, depth), want, f"{name} tile_prio {prio}")
+        assert_same(r.render(W, H, depth, 8, 24), want[8:24], f"{name} tile_prio {prio}, strip")
+    with pytest.raises(RtError):
+        r.set_option("tile_prio", 2)
+
+
 def test_heavy_tiles_on_a_tilted_horizon(oracle):
     """A camera rolled about its viewing axis: the horizon line is slanted, the band follows it column by column."""
     from scene_gen import build_sphere_field

@@ -81,6 +81,7 @@ struct rt_scene {
     int tile_z_log2 = -1;         /* wavefront tile height: -1 = auto (see launch()), else log2 */
     int block_threads_opt = 0;    /* 0 = auto */
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
+    int tile_prio_opt = -1;       /* OLD TILES FIRST: -1 = automatic (strips of at most a third of the width), 0 off, 1 on */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
     int help_opt = 1;             /* clustered scenes: wavefronts out of tiles help their workgroup's long shadow scans (0: they leave) */
     int heavy_opt = -1;           /* HEAVY tiles (the band of tile rows along the horizon line, one per workgroup, first): -1 = automatic, 0 = off, k = k - 1 rows either side */
@@ -843,7 +844,8 @@ int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, in
             return fail(RT_ERR_CAPACITY, "stack option: tables + bounce stack exceed 160 KiB LDS");
     } else if (s->stack_opt == 0) {
         /* the clustered-scene kernels run six wavefronts per SIMD (80 registers, no spills), the others seven */
-        const int share = (s->n_clusters > 0 && s->pairs_opt && s->cull_opt) ? 6 : RT_STACK_LDS_SHARE;
+        const int share256 = (s->n_clusters > 0 && s->pairs_opt && s->cull_opt) ? 6 : RT_STACK_LDS_SHARE;
+        const int share = std::max(1, share256 * 256 / *block);       /* (workgroups per CU: the same wavefronts in larger ones) */
         const double room = (double)(RT_MAX_LDS_BYTES / share) - (double)scene_bytes;
         in_lds = room > 0.0 ? std::floor(room / per_level) : 0.0;
         if (in_lds > levels) in_lds = levels;
@@ -996,6 +998,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
      * with the band, 4 strips 1.68 -> 1.63 ms); a whole frame has enough other tiles to run beside them, and giving three
      * of a workgroup's four wavefronts to one tile only costs it throughput (4.83 -> 5.02 ms; with a band of 0.9 % of the
      * height 5.32 ms).  profiles/r03_experiments.txt */
+    p.tile_prio = s->tile_prio_opt >= 0 ? s->tile_prio_opt : ((long long)(x1 - x0) * 3 <= (long long)W ? 1 : 0);
     const bool heavy_wanted = s->heavy_opt > 0 || (s->heavy_opt < 0 && (long long)(x1 - x0) * 3 <= (long long)W);
     if (p.help_rays_quads != 0 && heavy_wanted) {
         double dz_centre = 0.0;
@@ -1324,6 +1327,11 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "heavy")) {
         if (value < -1 || value > 4096) return fail(RT_ERR_INVALID, "heavy must be -1 (automatic), 0 (off) or 1 + the band's half-width in tile rows");
         s->heavy_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "tile_prio")) {
+        if (value < -1 || value > 1) return fail(RT_ERR_INVALID, "tile_prio must be -1 (automatic), 0 (off) or 1 (on)");
+        s->tile_prio_opt = value;
         return RT_OK;
     }
     if (!std::strcmp(key, "help_spin_limit")) {

@@ -958,6 +958,18 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
 #ifndef RT_PAIR_DIRECT_LANES
 #define RT_PAIR_DIRECT_LANES 32
 #endif
+#ifndef RT_BLOCK_BOUND
+#define RT_BLOCK_BOUND 256
+#endif
+/* OLD TILES FIRST.  Tiles take from 10 us to a millisecond, and a SIMD's five to seven resident wavefronts share its issue
+ * slots evenly: a long tile advances at a fifth of the speed it would have alone, and a launch short of tiles (one GPU's
+ * strip of a multi-GPU frame: 4-6 tiles per wavefront slot) ends with its long tiles running on while the slots around
+ * them have nothing left to start.  The long tiles are the ones whose rays go on bouncing, so a wavefront's priority on
+ * its SIMD (s_setprio) follows its tile's bounce level -- 1, 2, 3 from the first reflection on, back to 0 for the next
+ * tile: the old tile runs ahead of the young ones beside it, which finish later but are not what the launch waits for.
+ * No state (a clock-based age in a scalar register cost the 96-register kernel six more spilled VGPRs and whole frames
+ * 1-4 %).  RtParams::tile_prio; automatic for strips of at most a third of the image's width (whole frames lose about
+ * 1 % to it).  profiles/r03_experiments.txt, 14. */
 #ifndef RT_NT_STORES
 #define RT_NT_STORES 1           /* the image leaves through streaming stores (HBM bytes per built-in frame 272 -> 241 MB) */
 #endif
@@ -1502,6 +1514,11 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
     for (int level = 0; level <= p.max_depth; ++level) {
         if (__ballot(alive) == 0ull) break;
         levels = level + 1;
+        if (level >= 1 && level <= 3 && p.tile_prio != 0) {       /* OLD TILES FIRST */
+            if (level == 1) __builtin_amdgcn_s_setprio(1);
+            else if (level == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
         /* ---- phase 1 (per lane): nearest hit and the winner's CollisionObject ---- */
         bool shade = false;          /* this lane hit a non-light object and shades it */
         V3 P = o, N = d;
@@ -1665,6 +1682,7 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
         st_cycles(st, ST_CYCLES_REFLECT, t_reflect);
     }
 
+    if (p.tile_prio != 0) __builtin_amdgcn_s_setprio(0);
     /* unwind: final_k = local_k + (rf_k * C_{k+1}) * oc_k, inside-out (:601) */
     for (int k = levels - 1; k >= 0; --k) {
         if (k < top) {
@@ -1931,7 +1949,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 7
 #endif
-extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, RT_WAVES_PER_SIMD)
 rt_render_kernel(RT_KERNEL_ARGS) {
 #ifdef RT_FAST_PARAMS_BY_VALUE
     const RtParams &p = p_in_kernarg;
@@ -1942,14 +1960,14 @@ rt_render_kernel(RT_KERNEL_ARGS) {
 }
 
 /* the same over the two item tables: option "fast" = 0, and option "cull" = 0 (the plain in-order scans) */
-extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, RT_WAVES_PER_SIMD)
 rt_render_kernel_items(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
 }
 
 /* scenes whose tables are large (or do not fit LDS at all): the tables stay in global memory */
-extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD)
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, RT_WAVES_PER_SIMD)
 rt_render_kernel_large(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
@@ -1959,7 +1977,7 @@ rt_render_kernel_large(RT_KERNEL_ARGS) {
 #ifndef RT_WAVES_PER_SIMD_CLUSTERS
 #define RT_WAVES_PER_SIMD_CLUSTERS 6
 #endif
-extern "C" __global__ void __launch_bounds__(256, RT_WAVES_PER_SIMD_CLUSTERS)
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, RT_WAVES_PER_SIMD_CLUSTERS)
 rt_render_kernel_clusters(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
@@ -1967,7 +1985,7 @@ rt_render_kernel_clusters(RT_KERNEL_ARGS) {
 
 /* the same with the registers of five wavefronts per SIMD, for scenes whose tables leave room for no more than
  * five workgroups per CU anyway (the 1 024-sphere grid: 31.5 KB); the pair flush tests four members abreast here */
-extern "C" __global__ void __launch_bounds__(256, 5)
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, 5)
 rt_render_kernel_clusters_wide(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, true, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);

@@ -152,6 +152,8 @@ typedef struct RtParams {
      * (heavy_row0_q16 + tile column * heavy_slope_q16) >> 16 -- are rendered first, one per WORKGROUP: wavefront 0
      * renders, the others serve its shadow scans at the desk from the first scan on.  heavy_half < 0: none. */
     int32_t heavy_half, heavy_row0_q16, heavy_slope_q16;
+    /* OLD TILES FIRST (rt_kernel.hip): a wavefront's priority on its SIMD rises with the age of its tile (0: off) */
+    int32_t tile_prio;
     int32_t cull;                        /* 0: plain in-order scans (no bundle cull, no nearest-first exit); option "cull" */
     /* FAST tables (scenes without clustered sphere runs, option "fast"): see below */
     int32_t n_fast_items, n_fast_shadow; /* items in all; the first n_fast_shadow are the shadow scan's */
