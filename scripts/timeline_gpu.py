@@ -47,3 +47,14 @@ for a, b in zip(edges[:-1], edges[1:]):
     print(f"   t={mid:7.0f} us: tiles in flight {int(res.sum()):5d}, started in bin {int(sel.sum()):6d}, mean dur of those {dur[sel].mean() if sel.any() else 0:6.0f} us, max {dur[sel].max() if sel.any() else 0:6.0f}")
 h = np.histogram(dur[ok], bins=[0, 25, 50, 100, 200, 400, 800, 1600, 1e9])
 print("tile duration histogram (us):", dict(zip(["<25", "<50", "<100", "<200", "<400", "<800", "<1600", ">=1600"], h[0].tolist())))
+# per wavefront slot: when it got its first tile, when it ran out, how long it sat between tiles
+ids = who[ok].astype(np.int64); s_ = start[ok]; e_ = end[ok]
+order = np.lexsort((s_, ids))
+ids, s_, e_ = ids[order], s_[order], e_[order]
+first = np.r_[True, ids[1:] != ids[:-1]]; last = np.r_[ids[1:] != ids[:-1], True]
+gaps = (s_[1:] - e_[:-1])[~first[1:]]
+print(f"slots: first tile starts at {np.percentile(s_[first], [0, 10, 50, 90, 100]).round(1).tolist()} us (min/p10/median/p90/max); "
+      f"last tile ends at {np.percentile(e_[last], [0, 10, 50, 90, 100]).round(1).tolist()} us; "
+      f"gap between consecutive tiles of a slot: mean {gaps.mean():.2f} us, p90 {np.percentile(gaps, 90):.2f}, max {gaps.max():.1f}; tiles per slot mean {len(ids) / first.sum():.2f}")
+if os.environ.get("TIMELINE_DUMP"):
+    np.savez_compressed(os.environ["TIMELINE_DUMP"], start=start, end=end, who=who, heavy=heavy, ok=ok)

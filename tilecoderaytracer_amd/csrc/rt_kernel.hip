@@ -1731,6 +1731,22 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
     }
 }
 
+/* which of the tile queues still have tiles to hand out (bit q: queue q).  Its own function, called once per exhausted
+ * queue */
+#ifndef RT_SCAN_INLINE
+#define RT_SCAN_INLINE __forceinline__
+#endif
+__device__ RT_SCAN_INLINE unsigned int queues_with_tiles(const unsigned int *tile_counter, const int n_macros) {
+    const int lane = (int)(threadIdx.x & 63u);
+    int left = 0;
+    if (lane < RT_TILE_QUEUES) {
+        const int len_k = lane < n_macros ? ((n_macros - lane + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
+        const unsigned int taken = __hip_atomic_load(tile_counter + lane * RT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        left = len_k - (int)min(taken, 0x7fffffffu);
+    }
+    return (unsigned int)__builtin_amdgcn_ballot_w64(left > 0) & 0xFFu;
+}
+
 template <bool kStats, bool kGlobalTables = false, bool kClusters = false, bool kRoomy = false, bool kFast = false>
 __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__restrict__ image,
                                             float *__restrict__ out, unsigned int *__restrict__ tile_counter,
@@ -1827,6 +1843,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * millisecond after the queues had run dry); there the next tile is asked for when this one is done */
     const bool ask_ahead = !(kClusters || kStats) || p.n_clusters == 0;     /* the plain kernels: always */
     int steal = 0, next_pop = 0;
+    unsigned int candidates = ~0u;     /* the other queues that had tiles when this wavefront's own ran dry (~0: not looked yet) */
     bool fresh = true;                 /* the current queue has not been asked yet */
     for (;;) {
         int wave;                      /* tile number, row-major */
@@ -1861,7 +1878,28 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 fresh = false;
             }
             const int pop = __builtin_amdgcn_readfirstlane(next_pop);
-            if (pop >= queue_len) { ++steal; fresh = true; continue; }          /* next queue */
+            if (pop >= queue_len) {
+                /* This queue is through.  Which of the others still have tiles is found by ONE look at all the heads, when this
+                 * wavefront's own queue runs dry: an atomic on each exhausted queue in turn cost 3-4 us per queue -- 25 us
+                 * between a wavefront's last tile and its exit, or before the tile it finally found (a built-in strip's
+                 * timeline: the tiles that started last had waited that long for their wavefront to come by).  Heads only
+                 * grow: a queue seen empty stays empty, and the ones seen with tiles are then tried in ring order. */
+                if constexpr (kClusters || kStats || kGlobalTables) {
+                    /* (the clustered-scene kernels: tiles of 100 us, the walk is nothing next to them, and the few registers
+                     * of the look cost their frames 2.5 %; the large-scene kernel's 2 %) */
+                    ++steal;
+                } else {
+                    if (candidates == ~0u) {
+                        const unsigned int nonempty = queues_with_tiles(tile_counter, n_macros);                   /* bit q: queue q */
+                        candidates = ((nonempty >> my_xcc) | (nonempty << (RT_TILE_QUEUES - my_xcc))) & 0xFEu;     /* bit k: queue my_xcc + k */
+                    }
+                    if (candidates == 0u) break;
+                    steal = __builtin_ctz(candidates);
+                    candidates &= candidates - 1u;
+                }
+                fresh = true;
+                continue;
+            }
             if (ask_ahead && lane == 0) next_pop = (int)atomicAdd(head, 1u);
             const int macro = (pop / RT_MACRO_ROWS) * RT_TILE_QUEUES + queue;
             const int queued_row = macro / p.tiles_x;
