@@ -231,14 +231,16 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   nearest-first early exit, no sphere clustering, no
  *                   axis-aligned route (the slow baseline the fast path is
  *                   checked against, pixel for pixel, in tests/)
- *   "help"          1 (default) = scenes with clustered sphere runs: a wavefront that
- *                   has run out of tiles stays and tests candidate leaves of its
- *                   workgroup's long shadow scans (a desk in LDS, a shared cursor
- *                   over the candidates; blocking is an OR, so who tests which leaf
- *                   cannot change a pixel): shortens the end of a frame and, most
- *                   of all, of a GPU's strip of one; 0 = such wavefronts leave;
- *                   2..64 = on, and a scan asks for help from this many candidate
- *                   leaves on (default 8; tests use 2)
+ *   "help"          scenes with clustered sphere runs: 1 = a wavefront that has run out
+ *                   of tiles stays and tests candidate leaves of its workgroup's long
+ *                   shadow scans (a desk in LDS, a shared cursor over the candidates;
+ *                   blocking is an OR, so who tests which leaf cannot change a pixel):
+ *                   shortens the end of a GPU's strip of a frame; -1 (default) =
+ *                   automatic: on for launches of at most three quarters of the image's
+ *                   width (a whole frame pays 1 % for the owners' looks at the desk and
+ *                   ends well without help); 0 = such wavefronts leave; 2..64 = on, and
+ *                   a scan asks for help from this many candidate leaves on (default 8;
+ *                   tests use 2)
  *   "heavy"         scenes with clustered sphere runs under a horizon (with "help" on): the tiles
  *                   of the band of tile rows along the horizon line -- each keeps a wavefront
  *                   busy for a millisecond -- are rendered first, one per WORKGROUP (one
@@ -264,7 +266,8 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   64 items), 0 = by the bundle of rays like every other scan
  *   "tight_planes"  0 = plane items get the (much larger) padding of sphere items
  *   "aa_planes"     0 switches the axis-aligned rectangle route off
- *   "cluster_leaf"  spheres per leaf of a clustered run (default 16; 0 = no clustering) */
+ *   "cluster_leaf"  spheres per leaf of a clustered run (default -1 = by the run's length: 16 below 512
+ *                   spheres, 20 below 896, 24 below 3 000, else 32; 0 = no clustering) */
 int rt_set_option(rt_scene *scene, const char *key, int value);
 
 int         rt_device_count(int *count);

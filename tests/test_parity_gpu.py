@@ -778,14 +778,14 @@ def test_help_on_adversarial_scenes(oracle, seed):
 
 
 def test_help_on_and_off_render_the_same_strip_of_a_large_frame():
-    """4096^2 frame of the 1 024-sphere grid, the strip of GPU 3 of 8: help on (default), help from 2 leaves on, help off."""
+    """4096^2 frame of the 1 024-sphere grid, the strip of GPU 3 of 8: help on, help from 2 leaves on, help off, automatic (on: a strip)."""
     imgs = []
-    for value in (1, 2, 0):
+    for value in (1, 2, 0, -1):
         r = Renderer(HostScene.named("grid32"))
         r.set_option("help", value)
         imgs.append(r.render(4096, 4096, 4, 1536, 2048))
     assert imgs[0].shape == (512, 4096, 3)
-    for img, what in ((imgs[1], "help 2"), (imgs[2], "help off")):
+    for img, what in ((imgs[1], "help 2"), (imgs[2], "help off"), (imgs[3], "help automatic")):
         assert np.array_equal(imgs[0].view(np.uint32), img.view(np.uint32)), what
 
 
@@ -885,9 +885,10 @@ def test_help_timeout_path_is_exact_and_reported(oracle):
 def test_help_option_range():
     from tilecoderaytracer_amd import RtError
     r = Renderer(HostScene.named("grid9"))
-    for bad in (-1, 65):
+    for bad in (-2, 65):
         with pytest.raises(RtError):
             r.set_option("help", bad)
+    r.set_option("help", -1)          # automatic (the default): on for strips, off for whole frames
     assert r.render(16, 16, 2).shape == (16, 16, 3)
 
 

@@ -83,7 +83,7 @@ struct rt_scene {
     int stack_opt = 0;            /* bounce stack: 0 = auto, 1 = LDS, 2 = HBM */
     int tile_prio_opt = -1;       /* OLD TILES FIRST: -1 = automatic (strips of at most a third of the width), 0 off, 1 on */
     int first_row_permille = -1;  /* the tile queues start this far up the image (speed only); -1 = horizon_start() */
-    int help_opt = 1;             /* clustered scenes: wavefronts out of tiles help their workgroup's long shadow scans (0: they leave) */
+    int help_opt = -1;            /* clustered scenes: wavefronts out of tiles help their workgroup's long shadow scans (0: they leave; -1: on for strips) */
     int heavy_opt = -1;           /* HEAVY tiles (the band of tile rows along the horizon line, one per workgroup, first): -1 = automatic, 0 = off, k = k - 1 rows either side */
     int help_spin_opt = RT_HELP_SPIN_LIMIT;   /* the owner's bounded wait at its desk; -1: every wait counts as timed out (tests) */
     unsigned int *h_error = nullptr;          /* pinned host word the kernels can write: a HELP wait timed out */
@@ -97,7 +97,7 @@ struct rt_scene {
     int primary_opt = 1;          /* FAST tables: the camera rays' scan culls by projected pixel rectangles (PRIMARY table); 0: the bundle cull */
     int fast_opt = 1;             /* scenes without clustered runs: the kind-sorted item list with direct records (FAST tables); 0: the two item tables */
     int tight_planes = 1;         /* plane items: boxes padded for a plane's rounding only (RT_ITEM_TIGHT); 0: the sphere padding */
-    int cluster_leaf = 16;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering */
+    int cluster_leaf = -1;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering, -1 = by the run's length (auto_leaf()) */
     int cull_opt = 1;             /* 0: plain in-order scans -- no bundle cull, no nearest-first exit, no clustering, no AA route */
     int n_clusters = 0;
     /* tile queue heads, one per in-flight launch (same ring as the events) */
@@ -171,6 +171,16 @@ void split_leaves(const rt_object_desc *objs, std::vector<int> ids, int leaf, st
     split_leaves(objs, std::vector<int>(ids.begin() + (long)mid, ids.end()), leaf, out);
 }
 
+/* Spheres per leaf of a clustered run of n spheres.  A scan pays a box test per leaf it looks at and a member test per sphere
+ * of the leaves it opens: few large leaves for a long run, many small ones for a short one.  Measured on n x n sphere grids,
+ * 4096^2 depth 4, frame ms at 16 / 20 / 24 / 32 per leaf (scripts/sweep_gpu.py, profiles/r03_experiments.txt 16): 400 spheres
+ * 2.79 / 2.80 / 2.87 / 3.05; 576: 3.24 / 3.20 / 3.22 / 3.50; 784: 4.05 / 3.69 / 3.76 / 4.12; 1 024: 4.55 / 4.44 / 4.39 / 4.89;
+ * 2 304: 14.7 / 13.5 / 12.8 / 14.6; 3 969 (tables in global memory): 18.9 / 17.2 / 17.1 / 16.3.
+ * Leaves of 32 and more never go through the (ray, leaf) pair compaction (five bits for the member count), which only the
+ * clustered-scene kernels have: the largest size is for tables that are read from global memory anyway (two mirrors, 1024^2
+ * depth 50: 0.692 -> 0.626 ms there, but 0.445 -> 0.649 ms with its tables forced into LDS). */
+int auto_leaf(int n, bool tables_in_lds) { return n < 512 ? 16 : (n < 896 ? 20 : ((n < 3000 || tables_in_lds) ? 24 : 32)); }
+
 /* axis of a +-unit axis vector (other components exactly +-0), or -1 */
 int unit_axis(const float v[3], float *sign) {
     for (int k = 0; k < 3; ++k)
@@ -206,7 +216,7 @@ int pack_scene(rt_scene *s) {
     const rt_object_desc *objs = s->objects.data();
     const int sb = s->shadow_begin, se = s->shadow_end;
     /* option "cull" = 0: every object is a plain item in Scene index order */
-    const int cluster_leaf = s->cull_opt ? s->cluster_leaf : 0;
+    const int cluster_leaf_opt = s->cull_opt ? s->cluster_leaf : 0;
     const bool aa_planes = s->cull_opt && s->aa_planes;
 
     std::vector<Quad> geom, lights, mats, texs;
@@ -287,6 +297,7 @@ int pack_scene(rt_scene *s) {
         const int s0 = std::max(first, sb), s1 = std::min(last, se);
         const bool in_shadow_all = !sp.light && s0 == first && s1 == last;
         const bool in_shadow_none = sp.light || s0 >= s1;
+        const int cluster_leaf = cluster_leaf_opt < 0 ? auto_leaf(sp.count, s->tables_opt == 1) : cluster_leaf_opt;
         bool cluster = sp.kind == RT_KIND_SPHERE && cluster_leaf > 0 && sp.count >= 4 * cluster_leaf &&
                        (in_shadow_all || in_shadow_none);
         if (cluster)
@@ -964,7 +975,12 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     p.desk_off = 0;
     p.help_rays_quads = 0;
     p.help_leaves = s->help_opt >= 2 ? s->help_opt : RT_HELP_LEAVES;
-    if (clusters_kernel && s->help_opt && block > 64) {
+    /* automatic: for launches of at most three quarters of the image's width.  The owners' look at the desk before every long
+     * shadow scan costs a whole frame 1-1.4 % (grid-32 4.55 -> 4.49 ms, grid-16 d8 4.22 -> 4.17 without it), and a whole frame
+     * has tiles enough to end well without help; a strip does not (longest of 2 / 4 strips of the grid-32 frame: 2.79 / 1.53 ms
+     * with help, 3.10 / 2.28 without).  profiles/r03_experiments.txt 16 */
+    const bool help_wanted = s->help_opt > 0 || (s->help_opt < 0 && (long long)(x1 - x0) * 4 <= (long long)W * 3);
+    if (clusters_kernel && help_wanted && block > 64) {
         const int desk_off = p.stack_off + stack_lds_levels * block;
         const int with_desk = (desk_off + (RT_DESK_WORDS * 4 + 15) / 16) * 16;
         if ((size_t)with_desk <= RT_MAX_LDS_BYTES) {
@@ -1310,7 +1326,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
     if (!std::strcmp(key, "help")) {
-        if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "help must be 0 (off), 1 (on) or a number of candidate leaves, [2, 64]");
+        if (value < -1 || value > 64) return fail(RT_ERR_INVALID, "help must be -1 (automatic), 0 (off), 1 (on) or a number of candidate leaves, [2, 64]");
         s->help_opt = value;
         return RT_OK;
     }
@@ -1375,7 +1391,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     }
     if (!std::strcmp(key, "cull")) return repack_with(s->cull_opt, value != 0);
     if (!std::strcmp(key, "cluster_leaf")) {
-        if (value < 0 || value > 255) return fail(RT_ERR_INVALID, "cluster_leaf must be in [0, 255]");
+        if (value < -1 || value > 255) return fail(RT_ERR_INVALID, "cluster_leaf must be in [0, 255], or -1 (automatic)");
         return repack_with(s->cluster_leaf, value);
     }
     return fail(RT_ERR_INVALID, std::string("unknown option: ") + key);
