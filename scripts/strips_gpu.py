@@ -8,10 +8,13 @@ import torch
 S = 4096
 NS = tuple(int(a[2:]) for a in sys.argv[1:] if a.startswith("N=")) or (2, 4, 8)      # N=8 cut=0: equal strips of 8 only
 CUT = "cut=0" not in sys.argv[1:]
+ONLY = [a[5:].split(",") for a in sys.argv[1:] if a.startswith("only=")]
 for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8), ("grid32-noshadow", 4)]:
+    if ONLY and name not in ONLY[0]:
+        continue
     r = Renderer(HostScene.named(name))
     for a in sys.argv[1:]:
-        if "=" in a and not a.startswith(("N=", "cut=")):
+        if "=" in a and not a.startswith(("N=", "cut=", "only=")):
             r.set_option(a.split("=")[0], int(a.split("=")[1]))
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream().cuda_stream
