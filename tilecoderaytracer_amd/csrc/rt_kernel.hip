@@ -1466,7 +1466,8 @@ template <bool kStats, int kMode>
 __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays,
                                             const uint32_t *__restrict__ ctl_words, float *__restrict__ out,
                                             float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
-                                            Stats<kStats> &st, const int wave, const int my_xcc, const int steal) {
+                                            Stats<kStats> &st, const int wave_in, const int my_xcc, const int steal) {
+    const int wave = __builtin_amdgcn_readfirstlane(wave_in);      /* the tile number is the same in all lanes: a scalar register's worth */
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
     const int lane = (int)(threadIdx.x & 63u);
     unsigned long long t_start = 0ull, t_start_real = 0ull;
