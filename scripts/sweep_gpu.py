@@ -24,6 +24,8 @@ for a in sys.argv[3:]:
         r = Renderer(HostScene.named(name))
         try:
             r.set_option(k, int(v))
-            print(f"   {k}={v}: {t(r):.3f} ms", flush=True)
+            ms = t(r)
+            li = r.launch_info()
+            print(f"   {k}={v}: {ms:.3f} ms   ({li.kernel.decode()}, {li.lds_bytes} B LDS of which tables {li.scene_lds_bytes}, {li.grid_blocks} workgroups of {li.block_threads})", flush=True)
         except Exception as e:
             print(f"   {k}={v}: {type(e).__name__} {str(e)[:80]}", flush=True)
