@@ -251,8 +251,8 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   k - 1 tile rows either side
  *   "tile_prio"     a wavefront's priority on its SIMD follows the bounce level of its tile (the
  *                   tiles whose rays go on bouncing are the long ones, and a launch short of tiles
- *                   waits for them): -1 (default) = automatic, for strips of at most a third of
- *                   the image's width; 0 = off; 1 = on
+ *                   waits for them): -1 (default) = automatic, for strips of at most three fifths
+ *                   of the image's width; 0 = off; 1 = on
  *   "help_spin_limit" the bound of an owner's wait for helpers to leave its desk (default
  *                   2^22 polls); -1 makes every such wait count as timed out: the owner then
  *                   tests the leaves itself (same pixels), its workgroup stops helping, and

@@ -1014,7 +1014,10 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
      * with the band, 4 strips 1.68 -> 1.63 ms); a whole frame has enough other tiles to run beside them, and giving three
      * of a workgroup's four wavefronts to one tile only costs it throughput (4.83 -> 5.02 ms; with a band of 0.9 % of the
      * height 5.32 ms).  profiles/r03_experiments.txt */
-    p.tile_prio = s->tile_prio_opt >= 0 ? s->tile_prio_opt : ((long long)(x1 - x0) * 3 <= (long long)W ? 1 : 0);
+    /* (automatic: for strips of up to three fifths of the width -- halves re-cut by cost included.  Longest of 2 strips with /
+     * without: grid-32 2.48 / 2.66 ms, grid-16 d8 2.36 / 2.44, built-in 0.410 / 0.428; of 4: 1.50 / 1.52, 1.38 / 1.44, 0.274 /
+     * 0.323; whole frames lose 0.3-0.8 % to it) */
+    p.tile_prio = s->tile_prio_opt >= 0 ? s->tile_prio_opt : ((long long)(x1 - x0) * 5 <= (long long)W * 3 ? 1 : 0);
     const bool heavy_wanted = s->heavy_opt > 0 || (s->heavy_opt < 0 && (long long)(x1 - x0) * 3 <= (long long)W);
     if (p.help_rays_quads != 0 && heavy_wanted) {
         double dz_centre = 0.0;

@@ -968,7 +968,7 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
  * its SIMD (s_setprio) follows its tile's bounce level -- 1, 2, 3 from the first reflection on, back to 0 for the next
  * tile: the old tile runs ahead of the young ones beside it, which finish later but are not what the launch waits for.
  * No state (a clock-based age in a scalar register cost the 96-register kernel six more spilled VGPRs and whole frames
- * 1-4 %).  RtParams::tile_prio; automatic for strips of at most a third of the image's width (whole frames lose about
+ * 1-4 %).  RtParams::tile_prio; automatic for strips of up to three fifths of the image's width (whole frames lose about
  * 1 % to it).  profiles/r03_experiments.txt, 14. */
 #ifndef RT_NT_STORES
 #define RT_NT_STORES 1           /* the image leaves through streaming stores (HBM bytes per built-in frame 272 -> 241 MB) */
