@@ -1089,7 +1089,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
         if (kHelped && p.n_clusters > 0) {
             const int plain = min(max(p.shadow_first_leaf - base, 0), 64);
             const unsigned long long leaf_mask = plain >= 64 ? 0ull : (mask & ~((1ull << plain) - 1ull));
-            if constexpr (kHelped) {                                 /* HELP, above near_leaf_share() */
+            if constexpr (kHelped) {                                 /* HELP, above shadow_leaf_share() */
                 uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
                 if (p.help_rays_quads != 0 && __popcll(leaf_mask) >= p.help_leaves &&
                     (desk_read(desk, RT_DESK_FINISHED) != 0u || desk_read(desk, RT_DESK_DEDICATED) != 0u) &&
