@@ -1,6 +1,6 @@
 """Randomised parity sweep, GPU kernel vs CPU oracle (development aid; the permanent cases live in tests/).
 
-usage: fuzz_gpu.py [first_seed=1000] [count=200]"""
+usage: fuzz_gpu.py [first_seed=1000] [count=200] [only=0..3] [option=value ...]"""
 import os, sys, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,8 @@ kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 first, count = int(kv.get("first_seed", 1000)), int(kv.get("count", 200))
 bad, t0 = [], time.time()
 for seed in range(first, first + count):
+    if "only" in kv and seed % 4 != int(kv["only"]):    # only=0: the clustered sphere fields, only=1: the rooms
+        continue
     rng = np.random.RandomState(seed)
     if seed % 4 == 1:                   # axis-aligned rooms: rectangles, slabs, lights hugging surfaces, scales (round 3's culls)
         mk = lambda s: build_room(s, seed)
@@ -32,6 +34,9 @@ for seed in range(first, first + count):
     rng.set_state(state)
     orc = mk(oracle_lib.OracleScene())
     r = Renderer(host)
+    for k, v in kv.items():                             # any other key=value: an rt_set_option for every scene (help=2 heavy=1 ...)
+        if k not in ("first_seed", "count", "only"):
+            r.set_option(k, int(v))
     if seed % 3 == 0:
         r.set_option("tile_z", int(2 ** rng.randint(0, 7)))
     got, want = r.render(W, H, depth), orc.render(W, H, depth)
