@@ -142,6 +142,7 @@ def parse_args():
                          "'equal' keeps N equal strips")
     ap.add_argument("--no-overlap", action="store_true",
                     help="(accepted for compatibility; the headline at N > 1 is always the single-frame figure)")
+    ap.add_argument("--no-learn", action="store_true", help="N > 1: do not call rt_learn_tile_order for the ranks' strips")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1, single-frame mode: column chunks a strip is rendered and sent in (chunk k travels while "
                          "chunk k+1 is rendered); 0 = automatic from the measured kernel and transfer times, 1 = none")
@@ -462,6 +463,16 @@ def main():
                 partition_note = "balanced partition failed on another rank; equal strips"
             warm_left = max(warmup - 2, 1)       # at least one untimed frame on the final partition (first use of the links)
         x0, x1 = pipe.x0, pipe.x1
+        # N > 1, one launch per strip: where this rank's strip starts handing out its tile rows is learned from one counting frame
+        # and a few timed ones (rt_learn_tile_order; scheduling only, the pixels are the same; never loses the run)
+        learned = None
+        if world > 1 and chunks == 1 and x1 > x0 and not args.no_learn:
+            try:
+                renderer.learn_tile_order(W, H, depth, x0, x1)
+                learned = True
+            except Exception as e:
+                learned = f"unavailable ({e!r})"
+            fence()
 
         for _ in range(warm_left):
             pipe.step()
@@ -481,7 +492,9 @@ def main():
             elapsed, kernel_ms = float(t[0]), float(t[1])
         return dict(scene_name=scene_name, W=W, H=H, depth=depth, cfg_note=cfg_note, host=host, renderer=renderer,
                     x0=x0, x1=x1, strip=pipe.strip, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=kernel_ms,
-                    partition=pipe.describe(), partition_note=partition_note)
+                    partition=pipe.describe(),
+                    partition_note=(partition_note or "") + ("; tile rows of every strip start where rt_learn_tile_order measured best" if learned is True
+                                                             else (f"; rt_learn_tile_order {learned}" if learned else "")) or None)
 
     m = measure(args.workload, args.steps, args.warmup, args.size)
     scene_name, W, H, depth, cfg_note = m["scene_name"], m["W"], m["H"], m["depth"], m["cfg_note"]

@@ -196,6 +196,16 @@ int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, in
                     int max_depth, float *out_rgb, uint64_t *stats, int n_stats,
                     uint64_t *wave_cycles, int n_wave_cycles);
 
+
+/* Learn where this scene's launches of ONE shape start handing out their tile rows (speed only).  Renders that shape once with
+ * the counting build (about three times a frame's time; no pixels are returned) and keeps, per macro row (four tile rows), the
+ * longest tile and the rows' sums; every later rt_render / rt_render_device with the same W, H, x0, x1, max_depth and tile shape
+ * starts its queues a little before the row of the longest tile and sweeps towards the side where most of the cost lies,
+ * instead of by the start-row rule ("first_row" -1).  A launch that is short of tiles -- one GPU's strip of a multi-GPU frame --
+ * ends waiting for its longest tiles, and which they are is a matter of the scene and the camera (the previous frame knows).
+ * rt_set_option("learned_order", 0) forgets it; so does learning another shape.
+ * Replaces nothing in the reference (its workers pull pixels in index order, src/RayTracer.cpp:956-992). */
+int rt_learn_tile_order(rt_scene *scene, const rt_camera_desc *camera, int W, int H, int x0, int x1, int max_depth);
 /* Diagnostic BUILDS only (make -C tilecoderaytracer_amd/csrc variant NAME=timeline DEFS=-DRT_TIMELINE=1; the product
  * library refuses the option: the few instructions it takes cost the render kernels registers): with option
  * "timeline" = 1 every launch records, per wavefront tile in row-major order

@@ -14,11 +14,14 @@ for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8), ("grid32-noshadow"
         continue
     r = Renderer(HostScene.named(name))
     for a in sys.argv[1:]:
-        if "=" in a and not a.startswith(("N=", "cut=", "only=")):
+        if "=" in a and not a.startswith(("N=", "cut=", "only=", "learn=")):
             r.set_option(a.split("=")[0], int(a.split("=")[1]))
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream().cuda_stream
+    LEARN = "learn=1" in sys.argv[1:]                  # learn=1: rt_learn_tile_order for every strip before it is timed
     def t(x0, x1, n=3):
+        if LEARN and (x0, x1) != (0, S):
+            r.learn_tile_order(S, S, d, x0, x1)
         r.render_device(S, S, d, x0, x1, buf.data_ptr(), st); torch.cuda.synchronize()
         r.reset_timing()
         for _ in range(n):

@@ -109,6 +109,7 @@ def load_library():
     lib.rt_multi_set_option.argtypes = [vp, C.c_char_p, i]
     lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_render_stats.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, C.POINTER(C.c_uint64), i, vp, i]
+    lib.rt_learn_tile_order.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i]
     lib.rt_get_timing.argtypes = [vp, C.POINTER(RtTiming)]
     lib.rt_get_timeline.argtypes = [vp, vp, i]
     lib.rt_get_timeline.restype = i
@@ -116,7 +117,7 @@ def load_library():
     lib.rt_get_launch_info.argtypes = [vp, C.POINTER(RtLaunchInfo)]
     lib.rt_set_option.argtypes = [vp, C.c_char_p, i]
     for name in ("rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render",
-                 "rt_render_device", "rt_render_multi", "rt_render_stats", "rt_get_timing", "rt_reset_timing",
+                 "rt_render_device", "rt_render_multi", "rt_render_stats", "rt_learn_tile_order", "rt_get_timing", "rt_reset_timing",
                  "rt_get_launch_info", "rt_set_option", "rt_chunk_bounds", "rt_multi_create", "rt_multi_render",
                  "rt_multi_set_option", "rt_multi_destroy"):
         getattr(lib, name).restype = i

@@ -103,6 +103,11 @@ struct rt_scene {
     /* tile queue heads, one per in-flight launch (same ring as the events) */
     unsigned int *d_counters = nullptr;
     /* HELP: 2 KB per workgroup for the rays a wavefront publishes at its workgroup's desk */
+    /* LEARNED START ROW (rt_learn_tile_order): per macro row of one launch shape, its longest tile and its tiles' sum (cycles of
+     * the counting build) */
+    std::vector<double> row_peak, row_sum;     /* empty: nothing learned */
+    int order_key[6] = {0, 0, 0, 0, 0, 0};     /* W, H, x0, x1, max_depth, tile_z_log2 of the launch they were learned from */
+    int learned_sweep = -1;                    /* what rt_learn_tile_order measured to be fastest: -1 the rule, 0 from that row upwards, 1 downwards */
     void *d_help = nullptr;
     size_t d_help_bytes = 0;
     /* bounce stack in HBM: grid_blocks x (max_depth + 1) x block_threads entries of 16 B */
@@ -1039,6 +1044,38 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
             }
         }
     }
+    /* LEARNED START ROW (rt_learn_tile_order): the queues start a little before the macro row that held the longest tile of the
+     * counting frame -- outside the HEAVY band, whose tiles have their own queue -- and sweep towards the side where most of the
+     * frame's cost lies (rows in image order: long and short tiles stay interleaved on the SIMDs; rows sorted by cost measured
+     * slower, profiles/r03_experiments.txt 23) */
+    {
+        const int key[6] = {W, H, x0, x1, max_depth, tile_z_log2};
+        const long long macro_rows = (tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
+        if (!d_stats && s->first_row_permille < 0 && s->learned_sweep >= 0 && s->row_peak.size() == (size_t)macro_rows &&
+            std::equal(key, key + 6, s->order_key)) {
+            long long best = -1;
+            double weighted = 0.0, total = 0.0;
+            for (long long m = 0; m < macro_rows; ++m) {
+                bool in_band = false;
+                if (p.heavy_half >= 0) {
+                    const int mid_col = (int)(tiles_x / 2);
+                    const int line = (p.heavy_row0_q16 + mid_col * p.heavy_slope_q16) >> 16;
+                    const long long lo = (line - p.heavy_half - 1) / RT_MACRO_ROWS, hi = (line + p.heavy_half + 1) / RT_MACRO_ROWS;
+                    in_band = m >= lo && m <= hi;
+                }
+                weighted += s->row_sum[(size_t)m] * (double)m;
+                total += s->row_sum[(size_t)m];
+                if (!in_band && (best < 0 || s->row_peak[(size_t)m] > s->row_peak[(size_t)best])) best = m;
+            }
+            if (best >= 0 && total > 0.0) {
+                (void)weighted;
+                const bool upwards = s->learned_sweep == 0;
+                p.rows_downwards = upwards ? 0 : 1;
+                const long long margin = std::max<long long>(1, macro_rows / 64);
+                p.first_macro_row = (int)std::min(macro_rows - 1, std::max<long long>(0, upwards ? best - margin : best + margin));
+            }
+        }
+    }
     const bool clusters_wide = (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
     const bool fast_tables = s->base.n_fast_items > 0;
     struct Kernel { const void *fn; const char *name; };
@@ -1259,6 +1296,66 @@ int rt_render_stats(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0
     return RT_OK;
 }
 
+/* One frame of the counting build on this launch shape; per macro row its longest tile and its sum: later launches of the SAME
+ * shape (W, H, x0, x1, max_depth, tile shape) start their queues at the row of the longest tile (launch(), LEARNED START ROW). */
+int rt_learn_tile_order(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1, int max_depth) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 >= x1) return fail(RT_ERR_INVALID, "need 0 <= x0 < x1 <= W, W,H > 0");
+    int tzl;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        s->row_peak.clear(); s->row_sum.clear();
+        tzl = s->tile_z_log2 >= 0 ? s->tile_z_log2 : (s->objects.size() <= 128 ? 4 : 2);
+    }
+    const int tile_z = 1 << tzl, tile_x = 64 >> tzl;
+    const size_t tiles_z = (size_t)((H + tile_z - 1) / tile_z), tiles_x = (size_t)((x1 - x0 + tile_x - 1) / tile_x);
+    std::vector<uint64_t> stats(RT_STATS_COUNT), tiles(tiles_z * tiles_x * RT_TILE_STATS);
+    int rc = rt_render_stats(s, cam, W, H, x0, x1, max_depth, nullptr, stats.data(), RT_STATS_COUNT, tiles.data(), (int)tiles.size());
+    if (rc) return rc;
+    const size_t macro_rows = (tiles_z + RT_MACRO_ROWS - 1) / RT_MACRO_ROWS;
+    std::vector<double> peak(macro_rows, 0.0), sum(macro_rows, 0.0);
+    for (size_t row = 0; row < tiles_z; ++row)
+        for (size_t col = 0; col < tiles_x; ++col) {
+            const double c = (double)tiles[(row * tiles_x + col) * RT_TILE_STATS];
+            peak[row / RT_MACRO_ROWS] = std::max(peak[row / RT_MACRO_ROWS], c);
+            sum[row / RT_MACRO_ROWS] += c;
+        }
+    std::lock_guard<std::mutex> lock(s->mu);
+    const int key[6] = {W, H, x0, x1, max_depth, tzl};
+    std::copy(key, key + 6, s->order_key);
+    s->row_peak.swap(peak);
+    s->row_sum.swap(sum);
+    /* which sweep is fastest is MEASURED: the rule's, or from the longest tile's row upwards or downwards (three frames each
+     * into the handle's own buffer, the shortest counts); the rule stays unless a learned sweep beats it by 2 % */
+    HIP_TRY(hipSetDevice(s->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best_ms = 0.0f;
+    int best_sweep = -1;
+    rc = RT_OK;
+    for (int sweep = -1; sweep <= 1 && rc == RT_OK; ++sweep) {
+        s->learned_sweep = sweep;
+        float shortest = 1e30f;
+        for (int rep = 0; rep < 4 && rc == RT_OK; ++rep) {
+            hipError_t e = hipEventRecord(e0, nullptr);
+            if (e == hipSuccess) rc = launch(s, cam, W, H, x0, x1, max_depth, static_cast<float *>(s->d_fb), nullptr);
+            if (rc != RT_OK) break;
+            e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.0f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) { rc = fail(RT_ERR_HIP, hipGetErrorString(e)); break; }
+            if (rep > 0) shortest = std::min(shortest, ms);                 /* (the first one warms up) */
+        }
+        if (rc == RT_OK && (sweep < 0 || shortest < 0.98f * best_ms)) { best_ms = sweep < 0 ? shortest : std::min(best_ms, shortest); if (sweep >= 0) best_sweep = sweep; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    s->learned_sweep = rc == RT_OK ? best_sweep : -1;
+    return rc;
+}
+
 int rt_get_timing(const rt_scene *cs, rt_timing *out) {
     if (!cs || !out) return fail(RT_ERR_INVALID, "scene/out is NULL");
     rt_scene *s = const_cast<rt_scene *>(cs);
@@ -1346,6 +1443,11 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "heavy")) {
         if (value < -1 || value > 4096) return fail(RT_ERR_INVALID, "heavy must be -1 (automatic), 0 (off) or 1 + the band's half-width in tile rows");
         s->heavy_opt = value;
+        return RT_OK;
+    }
+    if (!std::strcmp(key, "learned_order")) {
+        if (value != 0) return fail(RT_ERR_INVALID, "learned_order accepts 0 only (forget the order of rt_learn_tile_order)");
+        s->row_peak.clear(); s->row_sum.clear();
         return RT_OK;
     }
     if (!std::strcmp(key, "tile_prio")) {

@@ -62,6 +62,11 @@ class Renderer:
                   "nearest_scans_1_16", "nearest_scans_17_32", "nearest_scans_33_48", "nearest_scans_49_64",
                   "nearest_scans_unculled", "nearest_unculled_box_tests", "nearest_unculled_sphere_tests", "nearest_sphere_tests")
 
+    def learn_tile_order(self, W, H, max_depth, x0=0, x1=None):
+        """rt_learn_tile_order: one frame of the counting build on this launch shape; later renders of the same shape hand their
+        tile rows out most expensive first (speed only; set_option("learned_order", 0) forgets it)."""
+        capi.check(self._lib.rt_learn_tile_order(self._scene, self._cam, W, H, x0, W if x1 is None else x1, max_depth))
+
     def render_stats(self, W, H, max_depth, x0=0, x1=None, wave_cycles=False):
         """Counting build: returns (image, {counter: value}[, per wavefront tile (tiles_z, tiles_x, 6) = cycles, sphere tests, box tests, scans, start, end (100 MHz)])."""
         x1 = W if x1 is None else x1
