@@ -203,7 +203,8 @@ int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, in
  * starts its queues a little before the row of the longest tile and sweeps towards the side where most of the cost lies,
  * instead of by the start-row rule ("first_row" -1).  A launch that is short of tiles -- one GPU's strip of a multi-GPU frame --
  * ends waiting for its longest tiles, and which they are is a matter of the scene and the camera (the previous frame knows).
- * rt_set_option("learned_order", 0) forgets it; so does learning another shape.
+ * The call also times a dozen frames of that shape into the handle's own buffer to decide (they count in rt_get_timing:
+ * rt_reset_timing afterwards).  rt_set_option("learned_order", 0) forgets it; so does learning another shape.
  * Replaces nothing in the reference (its workers pull pixels in index order, src/RayTracer.cpp:956-992). */
 int rt_learn_tile_order(rt_scene *scene, const rt_camera_desc *camera, int W, int H, int x0, int x1, int max_depth);
 /* Diagnostic BUILDS only (make -C tilecoderaytracer_amd/csrc variant NAME=timeline DEFS=-DRT_TIMELINE=1; the product
