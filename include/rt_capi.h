@@ -200,10 +200,11 @@ int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, in
 /* Learn where this scene's launches of ONE shape start handing out their tile rows (speed only).  Renders that shape once with
  * the counting build (about three times a frame's time; no pixels are returned) and keeps, per macro row (four tile rows), the
  * longest tile and the rows' sums; every later rt_render / rt_render_device with the same W, H, x0, x1, max_depth and tile shape
- * starts its queues a little before the row of the longest tile and sweeps towards the side where most of the cost lies,
- * instead of by the start-row rule ("first_row" -1).  A launch that is short of tiles -- one GPU's strip of a multi-GPU frame --
+ * starts its queues a little before the row of the longest tile, sweeping up or down, instead of by the start-row rule
+ * ("first_row" -1) -- if that measured faster: the call times the rule's sweep and the two learned ones and keeps a learned one
+ * only if it beats the rule by 3 %.  A launch that is short of tiles -- one GPU's strip of a multi-GPU frame --
  * ends waiting for its longest tiles, and which they are is a matter of the scene and the camera (the previous frame knows).
- * The call also times a dozen frames of that shape into the handle's own buffer to decide (they count in rt_get_timing:
+ * The timed frames (about twenty) go into the handle's own buffer (they count in rt_get_timing:
  * rt_reset_timing afterwards).  rt_set_option("learned_order", 0) forgets it; so does learning another shape.
  * Replaces nothing in the reference (its workers pull pixels in index order, src/RayTracer.cpp:956-992). */
 int rt_learn_tile_order(rt_scene *scene, const rt_camera_desc *camera, int W, int H, int x0, int x1, int max_depth);

@@ -1325,19 +1325,18 @@ int rt_learn_tile_order(rt_scene *s, const rt_camera_desc *cam, int W, int H, in
     std::copy(key, key + 6, s->order_key);
     s->row_peak.swap(peak);
     s->row_sum.swap(sum);
-    /* which sweep is fastest is MEASURED: the rule's, or from the longest tile's row upwards or downwards (three frames each
-     * into the handle's own buffer, the shortest counts); the rule stays unless a learned sweep beats it by 2 % */
+    /* What is fastest for this shape is MEASURED (seven frames per candidate into the handle's own buffer, the first warms up,
+     * the shortest of the others counts; a candidate replaces the best so far only if it beats it by 3 %): the rule's sweep, or
+     * from the longest tile's row upwards or downwards.  (Trying the HEAVY band and the tile priorities the other way round per
+     * shape as well gave nothing beyond the strip model's +-4 %: profiles/r03_experiments.txt 23-24) */
     HIP_TRY(hipSetDevice(s->device));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    float best_ms = 0.0f;
-    int best_sweep = -1;
     rc = RT_OK;
-    for (int sweep = -1; sweep <= 1 && rc == RT_OK; ++sweep) {
-        s->learned_sweep = sweep;
+    auto frame_ms = [&]() {
         float shortest = 1e30f;
-        for (int rep = 0; rep < 4 && rc == RT_OK; ++rep) {
+        for (int rep = 0; rep < 7 && rc == RT_OK; ++rep) {
             hipError_t e = hipEventRecord(e0, nullptr);
             if (e == hipSuccess) rc = launch(s, cam, W, H, x0, x1, max_depth, static_cast<float *>(s->d_fb), nullptr);
             if (rc != RT_OK) break;
@@ -1346,13 +1345,21 @@ int rt_learn_tile_order(rt_scene *s, const rt_camera_desc *cam, int W, int H, in
             float ms = 0.0f;
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
             if (e != hipSuccess) { rc = fail(RT_ERR_HIP, hipGetErrorString(e)); break; }
-            if (rep > 0) shortest = std::min(shortest, ms);                 /* (the first one warms up) */
+            if (rep > 0) shortest = std::min(shortest, ms);
         }
-        if (rc == RT_OK && (sweep < 0 || shortest < 0.98f * best_ms)) { best_ms = sweep < 0 ? shortest : std::min(best_ms, shortest); if (sweep >= 0) best_sweep = sweep; }
+        return shortest;
+    };
+    s->learned_sweep = -1;
+    float best_ms = frame_ms();
+    for (int sweep = 0; sweep <= 1 && rc == RT_OK; ++sweep) {
+        const int keep = s->learned_sweep;
+        s->learned_sweep = sweep;
+        const float ms = frame_ms();
+        if (rc == RT_OK && ms < 0.97f * best_ms) best_ms = ms; else s->learned_sweep = keep;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    s->learned_sweep = rc == RT_OK ? best_sweep : -1;
+    if (rc != RT_OK) s->learned_sweep = -1;
     return rc;
 }
 
