@@ -35,10 +35,12 @@ for seed in range(first, first + count):
     orc = mk(oracle_lib.OracleScene())
     r = Renderer(host)
     for k, v in kv.items():                             # any other key=value: an rt_set_option for every scene (help=2 heavy=1 ...)
-        if k not in ("first_seed", "count", "only"):
+        if k not in ("first_seed", "count", "only", "learn"):
             r.set_option(k, int(v))
     if seed % 3 == 0:
         r.set_option("tile_z", int(2 ** rng.randint(0, 7)))
+    if kv.get("learn") == "1" and W > 0 and H > 0:      # learn=1: rt_learn_tile_order for the shape before it is rendered
+        r.learn_tile_order(W, H, depth)
     got, want = r.render(W, H, depth), orc.render(W, H, depth)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
         d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
