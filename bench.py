@@ -20,8 +20,11 @@ measured cost (--partition balanced, the default): the first two warm-up steps
 kernel time and the time of a gather on its own; the image is then re-cut so
 that rank 0 -- which receives and sends nothing -- renders as long as a peer
 needs to render and ship its columns (tilecoderaytracer_amd/distributed.py:
-balanced_bounds).  All W warm-up steps are untimed; the K timed steps all run
-the final partition.  The throughput of a STREAM of frames (gather of frame k
+balanced_bounds).  When a strip is one launch, each rank then lets the library
+measure where that launch shape should start handing out its tile rows
+(rt_learn_tile_order: one counting frame and twenty timed ones, before the
+timed region; --no-learn skips it; scheduling only, same pixels).  All W
+warm-up steps are untimed; the K timed steps all run the final partition.  The throughput of a STREAM of frames (gather of frame k
 under the render of frame k+1) is measured afterwards and reported beside the
 headline as `pipelined`, labelled as a different figure.
 
