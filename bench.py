@@ -4,8 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 A "step" is one full render of the workload image.  At N = 1 the whole image
-is one kernel launch on one GPU.  At N > 1 (one process per GPU, launched with
-torch.distributed.run) the image is split into N contiguous x-strips
+is one kernel launch on one GPU.  At N > 1 there is one process per GPU: started
+by the driver with torch.distributed.run, or -- `python bench.py --gpus N` with no
+rank variables in the environment -- by this file itself, which starts
+`python -m torch.distributed.run ... bench.py --gpus N ...` as a child process
+before it has imported torch or touched HIP, relays rank 0's JSON line and exits
+with the child's code (self_launch(); the reference's main() spawns its own ranks
+too, src/RayTracer.cpp:1536-1566).  The image is split into N contiguous x-strips
 (the framebuffer is x-major, pixels[x][z], so a strip is one contiguous
 block), every rank renders its strip into HBM and the strips travel to rank 0
 over RCCL (torch.distributed backend "nccl") -- STRONG scaling: the image is
@@ -121,7 +126,7 @@ def valu_issue_roofline(rec, kernel_ms):
     }
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -151,7 +156,7 @@ def parse_args():
                          "chunk k+1 is rendered); 0 = automatic from the measured kernel and transfer times, 1 = none")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="N > 1: skip the second, pipelined measurement (gather of frame k under the render of frame k+1)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def host_cores():
@@ -356,8 +361,77 @@ def shipped_workload(args):
     print(json.dumps(out), flush=True)
 
 
-def main():
-    args = parse_args()
+def free_port():
+    """A TCP port nobody listens on right now (the rendezvous of the ranks this process starts)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(gpus, argv, port):
+    """argv of the child that runs `gpus` ranks of this file, one per GPU, over RCCL: what the reference's main() does
+    with ilib_proc_exec (src/RayTracer.cpp:1536-1566: the first process spawns the others and they meet at a barrier).
+    TCRT_BENCH_LAUNCHER (tests) replaces `python -m torch.distributed.run` by another program with the same arguments."""
+    launcher = os.environ.get("TCRT_BENCH_LAUNCHER")
+    head = launcher.split() if launcher else [sys.executable, "-m", "torch.distributed.run"]
+    return head + ["--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                   os.path.abspath(__file__)] + list(argv)
+
+
+def launch_environment(environ=None):
+    """The children's environment: marked as started from here (never a second generation), dmabuf IPC as this pool's
+    driver needs for RCCL between processes, and no rank variables inherited from whoever started this process."""
+    env = dict(os.environ if environ is None else environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["TCRT_BENCH_CHILD"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def result_lines(text):
+    """The bench lines in a child's stdout: JSON objects that carry "metric" (anything else a launcher or a library
+    printed there is noise and goes to stderr)."""
+    found, noise = [], []
+    for line in text.splitlines():
+        s = line.strip()
+        ok = False
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                ok = "metric" in json.loads(s)
+            except ValueError:
+                ok = False
+        (found if ok else noise).append(line)
+    return found, noise
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: start the N ranks as a CHILD process -- before this process has
+    imported torch or touched HIP, and never by exec (a process that has initialised the GPU must not be replaced) --,
+    relay rank 0's single JSON line on stdout, everything else on stderr, and return the child's exit code."""
+    import subprocess
+    assert "torch" not in sys.modules, "the launcher must not have initialised torch / HIP"
+    cmd = launch_command(args.gpus, argv, free_port())
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=launch_environment(), text=True)
+    found, noise = result_lines(child.stdout or "")
+    for line in noise:
+        print(line, file=sys.stderr)
+    sys.stderr.flush()
+    if child.returncode != 0:
+        print(f"bench.py: the ranks failed (exit code {child.returncode})", file=sys.stderr, flush=True)
+        return child.returncode
+    if len(found) != 1:
+        print(f"bench.py: expected one result line from rank 0, got {len(found)}", file=sys.stderr, flush=True)
+        return 1
+    print(found[0], flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
     if args.workload in ("shipped", "shipped512"):
         if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
             sys.exit("the shipped workloads time one process on one GPU")
@@ -366,10 +440,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                     f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
-                     f"--master-addr 127.0.0.1 --master-port <P> bench.py --gpus {args.gpus} ...")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ and not os.environ.get("TCRT_BENCH_CHILD"):
+            sys.exit(self_launch(args, argv))          # one process per GPU: started from here
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import torch
@@ -427,7 +499,7 @@ def main():
 
         # chunks: given, or decided with the partition below (automatic); one GPU: only if asked for
         chunks = args.chunks if (args.chunks > 0 and not overlap) else 1
-        pipe = make_pipe(chunks=chunks if world == 1 else 1)
+        pipe = make_pipe(chunks=chunks if world == 1 else 1)     # N > 1: the measuring frames run unchunked equal strips
 
         def fence():
             pipe.drain()
@@ -451,19 +523,23 @@ def main():
             tm = renderer.timing()
             my_kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
             bounds = None
+            agreed_chunks = None
             try:
-                bounds, partition_note = measure_and_balance(pipe, W, my_kernel_ms, fence, dev, overlap=overlap,
-                                                             chunks=0 if (args.chunks == 0 and not overlap) else chunks)
-                chunks = measure_and_balance.last_chunks
+                bounds, partition_note, agreed_chunks = measure_and_balance(
+                    pipe, W, my_kernel_ms, fence, dev, overlap=overlap,
+                    chunks=0 if (args.chunks == 0 and not overlap) else chunks)
             except Exception as e:                                         # never lose the run to the tuning step
                 partition_note = f"balanced partition unavailable ({e!r}); equal strips"
-            # all ranks take the new strips, or none does
+            # all ranks take the new strips and chunk count, or none does: `chunks` is the same number on every rank either way
             ok = torch.tensor([1 if bounds is not None else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok[0]) == 1:
+                chunks = agreed_chunks
                 pipe = make_pipe(bounds, chunks)
-            elif bounds is not None:
-                partition_note = "balanced partition failed on another rank; equal strips"
+            else:
+                if bounds is not None:
+                    partition_note = "balanced partition failed on another rank; equal strips"
+                pipe = make_pipe(chunks=chunks)            # what the command line asked for (or none), on every rank
             warm_left = max(warmup - 2, 1)       # at least one untimed frame on the final partition (first use of the links)
         x0, x1 = pipe.x0, pipe.x1
         # N > 1, one launch per strip: where this rank's strip starts handing out its tile rows is learned from one counting frame
@@ -487,14 +563,19 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         tm = renderer.timing()
-        kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)
-        own_kernel_ms = kernel_ms                      # this rank's launches (the roofline pairs it with this rank's pixels)
+        # a chunked strip is several launches per frame: the roofline pairs ONE launch's average duration with ONE
+        # launch's share of the strip's pixels; the frame's kernel time is the sum over its launches
+        own_kernel_ms = tm.sum_kernel_ms / max(tm.launches, 1)       # this rank's average launch
+        launches_per_frame = tm.launches / max(steps, 1)
+        frame_kernel_ms = tm.sum_kernel_ms / max(steps, 1)
+        max_frame_kernel_ms = frame_kernel_ms
         if use_dist:
-            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed, frame_kernel_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, kernel_ms = float(t[0]), float(t[1])
+            elapsed, max_frame_kernel_ms = float(t[0]), float(t[1])
         return dict(scene_name=scene_name, W=W, H=H, depth=depth, cfg_note=cfg_note, host=host, renderer=renderer,
-                    x0=x0, x1=x1, strip=pipe.strip, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=kernel_ms,
+                    x0=x0, x1=x1, strip=pipe.strip, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=max_frame_kernel_ms,
+                    launches_per_frame=launches_per_frame, frame_kernel_ms=frame_kernel_ms,
                     partition=pipe.describe(),
                     partition_note=(partition_note or "") + ("; tile rows of every strip start where rt_learn_tile_order measured best" if learned is True
                                                              else (f"; rt_learn_tile_order {learned}" if learned else "")) or None)
@@ -538,7 +619,8 @@ def main():
 
     if rank == 0:
         li = renderer.launch_info()
-        pixels_per_launch = (x1 - x0) * H
+        launches_per_frame = m["launches_per_frame"] or 1.0
+        pixels_per_launch = (x1 - x0) * H / launches_per_frame       # a strip sent in K chunks is K launches per frame
         achieved = BYTES_PER_PIXEL * pixels_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_source, compute = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -599,7 +681,9 @@ def main():
                 "traffic_source": traffic_source,
                 "compute": compute,
                 "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels_per_launch,
+                "launches_per_frame": round(launches_per_frame, 3),
+                "frame_kernel_ms": round(m["frame_kernel_ms"], 4),
+                "algorithmic_bytes_per_launch": round(BYTES_PER_PIXEL * pixels_per_launch, 1),
                 "note": "12 B/pixel framebuffer store is the only HBM traffic that scales with the image; "
                         "the kernel is bound by fp32 (non-FMA) instruction issue, see DESIGN.md",
             },

@@ -29,7 +29,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
-    assert r["algorithmic_bytes_per_launch"] == 4096 * 4096 * 12
+    assert r["algorithmic_bytes_per_launch"] == 4096 * 4096 * 12 and r["launches_per_frame"] == 1.0
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
@@ -53,7 +53,15 @@ def test_bench_force_dist_runs_the_chunked_single_frame_path_on_one_gpu():
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
     assert "4 column chunks" in j["config"]["partition"] and j["value"] > 10.0
-    assert j["roofline"]["kernel"].startswith("rt_render_kernel_clusters")
+    r = j["roofline"]
+    assert r["kernel"].startswith("rt_render_kernel_clusters")
+    # four launches per frame: a launch's share of the pixels over a launch's average duration, which is the frame's
+    # pixels over the frame's kernel time -- not the whole strip over one chunk's time
+    assert r["launches_per_frame"] == 4.0
+    assert abs(r["algorithmic_bytes_per_launch"] - 512 * 512 * 12 / 4) < 1.0
+    assert abs(r["frame_kernel_ms"] - 4 * r["kernel_ms"]) < 0.02 * r["frame_kernel_ms"] + 1e-3
+    assert abs(r["achieved"] - 12 * 512 * 512 / (r["frame_kernel_ms"] * 1e-3) / 1e9) < 0.03 * r["achieved"] + 1e-3
+    assert r["frame_kernel_ms"] <= j["ms_per_step"] * 1.05
 
 
 @pytest.mark.gpu

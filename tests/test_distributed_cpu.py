@@ -293,7 +293,8 @@ def _balance_worker(rank, world, W, H, init_file, out_file):
     pipe.step()
     pipe.step()
     fake_kernel_ms = [1.0, 3.0, 1.0][rank]               # the middle strip is the expensive one
-    bounds, note = measure_and_balance(pipe, W, fake_kernel_ms, sync, "cpu")
+    bounds, note, chunks = measure_and_balance(pipe, W, fake_kernel_ms, sync, "cpu")
+    assert chunks == 1                                    # overlap mode never chunks
     pipe = make(bounds)
     for _ in range(3):
         pipe.step()

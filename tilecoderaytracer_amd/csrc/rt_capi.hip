@@ -1417,8 +1417,8 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return RT_OK;
     }
     if (!std::strcmp(key, "block_threads")) {
-        if (value != 0 && (value < 64 || value > 512 || (value % 64) != 0))        /* launch() refuses what exceeds the chosen kernel's launch bounds */
-            return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or a multiple of 64 up to 512 (the render kernels take up to 256)");
+        if (value != 0 && (value < 64 || value > 1024 || (value % 64) != 0))       /* launch() refuses what exceeds the chosen kernel's launch bounds */
+            return fail(RT_ERR_INVALID, "block_threads must be 0 (auto) or a multiple of 64 up to 1024 (a launch refuses more than its kernel's launch bounds)");
         s->block_threads_opt = value;
         return RT_OK;
     }

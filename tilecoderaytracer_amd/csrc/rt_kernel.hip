@@ -2024,7 +2024,10 @@ rt_render_kernel_clusters(RT_KERNEL_ARGS) {
 
 /* the same with the registers of five wavefronts per SIMD, for scenes whose tables leave room for no more than
  * five workgroups per CU anyway (the 1 024-sphere grid: 31.5 KB); the pair flush tests four members abreast here */
-extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, 5)
+#ifndef RT_WAVES_PER_SIMD_WIDE
+#define RT_WAVES_PER_SIMD_WIDE 5
+#endif
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, RT_WAVES_PER_SIMD_WIDE)
 rt_render_kernel_clusters_wide(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, true, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);

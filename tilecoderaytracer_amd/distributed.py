@@ -161,8 +161,10 @@ def measure_and_balance(pipe, W, my_kernel_ms, sync, device, overlap=True, chunk
     """Called by every rank between two warm-up frames on the EQUAL partition.
     Times one gather on its own (nothing else in flight; `sync()` must drain the
     device and end with a barrier), shares every rank's kernel time, and returns
-    (bounds, note): the measured-cost partition of balanced_bounds() -- the same
-    on every rank -- and a sentence for the bench record."""
+    (bounds, note, chunks): the measured-cost partition of balanced_bounds() and
+    the chunk count it was cut for (`chunks` as given, or -- 0 -- suggest_chunks()
+    of what was measured), both the same on every rank, and a sentence for the
+    bench record."""
     import time
     import numpy as np
     world = dist.get_world_size()
@@ -188,8 +190,7 @@ def measure_and_balance(pipe, W, my_kernel_ms, sync, device, overlap=True, chunk
     note = (f"re-cut after warm-up frames on the equal partition: kernel ms per rank "
             f"{[round(k, 3) for k in kernel_by_rank]}, gather alone {gather_ms:.3f} ms"
             + (f"; every strip rendered and sent in {chunks} column chunks" if chunks > 1 else ""))
-    measure_and_balance.last_chunks = chunks
-    return bounds, note
+    return bounds, note, chunks
 
 
 class StripPipeline:
