@@ -16,6 +16,11 @@
  * src/Scene.cpp:386, src/RayTracer.cpp:862-873, 2027-2031); nothing throws or
  * aborts across the ABI; rt_last_error() gives the text for the calling thread.
  *
+ * This header is the whole drop-in surface: scenes, renders, the multi-GPU
+ * partition, timing, errors.  Speed-only options, the counting build and the
+ * diagnostic calls live in rt_capi_tuning.h (its own version number); nothing
+ * a maintainer of the reference needs is there.
+ *
  * There is NO CPU fallback behind this ABI.  If no HIP device is usable every
  * call that needs one fails with RT_ERR_NO_DEVICE.
  */
@@ -28,7 +33,8 @@
 extern "C" {
 #endif
 
-#define RT_CAPI_VERSION 2      /* 2: rt_multi_*, rt_chunk_bounds, rt_get_timeline; the second pass ("defer") is gone */
+#define RT_CAPI_VERSION 3      /* 3: strips cut by measured cost (rt_multi_render chunks = 0, rt_balance_strips, rt_suggest_chunks,
+                                * rt_multi_set_bounds, rt_multi_get_info); options, counters and calibration moved to rt_capi_tuning.h */
 
 enum {
     RT_OK = 0,
@@ -101,15 +107,6 @@ typedef struct rt_timing {
     double   last_download_ms;  /* device->host copy in rt_render (0 for rt_render_device)              */
 } rt_timing;
 
-typedef struct rt_launch_info {
-    int32_t block_threads;      /* threads per workgroup                                        */
-    int32_t lds_bytes;          /* dynamic LDS per workgroup (scene tables + bounce stack)      */
-    int32_t scene_lds_bytes;    /* of which scene tables                                        */
-    int32_t grid_blocks;        /* workgroups of the last launch                                */
-    int32_t tile_x, tile_z;     /* pixels per wavefront tile (tile_x * tile_z == 64)            */
-    char    kernel[48];         /* name of the __global__ function the last launch ran (its first pass) */
-} rt_launch_info;
-
 /* Replaces: the Scene the reference keeps in the global my_scene
  * (src/RayTracer.h:50) -- copies the description, uploads the tables to
  * `device`.  The caller keeps ownership of *desc. */
@@ -135,152 +132,78 @@ int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, int W, int H,
 
 /* Replaces: the reference's static partitioning (strategy 1,
  * src/RayTracer.cpp:904-923 with CORE_NUM > 1) across the GPUs of one node,
- * single process: contiguous x-strips, one per GPU, gathered to device 0 with
- * ncclGather over xGMI, then copied to out_rgb (host, whole image). */
+ * single process: contiguous x-strips, one per GPU, each GPU's columns sent to
+ * device 0 over its own xGMI link (ncclSend / ncclRecv) while it renders the next
+ * ones, then copied to out_rgb (host, whole image).  The strips are cut by
+ * measured cost and sent in as many column chunks as the measurement suggests
+ * (rt_multi_render with chunks = 0, below): create + render + destroy. */
 int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W, int H,
                     int max_depth, int ngpu, float *out_rgb);
 
 /* The same with everything that can survive from frame to frame kept in a handle: the per-GPU
- * scenes, two streams per GPU, the strip buffers, the image on device 0 and the RCCL communicator
- * (rt_render_multi = create + render + destroy).  rt_multi_render renders and sends every strip in
- * `chunks` column chunks (1..64): chunk k travels to device 0 on the GPU's communication stream
- * (ncclSend / ncclRecv) while its compute stream renders chunk k+1 -- within one frame, the way the
- * reference's ranks write into the shared `pixels` while they render (src/RayTracer.cpp:904-923,
- * 1188-1193).  Every chunk is a kernel launch of its own: 1 is right where a strip's kernel is long
- * next to its transfer, 4..8 where the transfer is as long as the kernel (the built-in scene). */
+ * scenes, two streams per GPU, the strip buffers, the image on device 0, the RCCL communicator and
+ * the partition.  rt_multi_render renders and sends every strip in `chunks` column chunks: chunk k
+ * travels to device 0 on the GPU's communication stream (ncclSend / ncclRecv) while its compute
+ * stream renders chunk k+1 -- within one frame, the way the reference's ranks write into the shared
+ * `pixels` while they render (src/RayTracer.cpp:904-923, 1188-1193).  Every chunk is a kernel launch
+ * of its own: 1 is right where a strip's kernel is long next to its transfer, 4..8 where the
+ * transfer is as long as the kernel (the built-in scene).
+ *   chunks = 1..64  that many, on equal strips (rt_strip_bounds) or the strips of rt_multi_set_bounds
+ *   chunks = 0      automatic.  The first such call for a frame shape (W, H, max_depth, camera) renders
+ *                   three extra frames on equal strips -- one to warm up, the kernels alone, the
+ *                   transfers alone -- and cuts the strips so that device 0, which receives and sends
+ *                   nothing, renders as long as a peer needs to render and ship its columns
+ *                   (rt_balance_strips), with rt_suggest_chunks's chunk count; later calls of the same
+ *                   shape reuse the cut.  The image is the same for every partition.
+ * A failed frame leaves nothing queued on any GPU and no RCCL group open; after a failed RCCL call
+ * the handle refuses further frames (RT_ERR_RCCL): destroy it. */
+#define RT_MULTI_MAX_GPUS 16
 typedef struct rt_multi rt_multi;
+typedef struct rt_multi_info {                      /* of the last rt_multi_render */
+    int32_t ngpu, chunks;
+    int32_t balanced;                               /* 1: the strips were cut by measured cost */
+    int32_t bounds[RT_MULTI_MAX_GPUS + 1];          /* GPU g rendered columns [bounds[g], bounds[g + 1]) */
+    double  kernel_ms[RT_MULTI_MAX_GPUS];           /* per GPU: its kernels of that frame (HIP events) */
+    double  frame_ms;                               /* host clock: first enqueue until everything was on device 0 */
+    double  measured_kernel_ms[RT_MULTI_MAX_GPUS];  /* what the cut was computed from: every GPU's equal strip ... */
+    double  measured_gather_ms;                     /* ... and the equal strips' transfers on their own */
+} rt_multi_info;
 int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **out);
 int rt_multi_render(rt_multi *multi, const rt_camera_desc *cam, int W, int H, int max_depth,
                     int chunks, float *out_rgb);
-int rt_multi_set_option(rt_multi *multi, const char *key, int value);   /* rt_set_option on every GPU's scene */
+/* strips given by the caller for images W wide: GPU g renders columns [bounds[g], bounds[g + 1]), bounds[0] = 0,
+ * bounds[ngpu] = W, non-decreasing (empty strips allowed); `chunks` is what rt_multi_render(chunks = 0) then uses.
+ * bounds = NULL: back to equal strips / the measured cut. */
+int rt_multi_set_bounds(rt_multi *multi, int W, const int *bounds, int chunks);
+int rt_multi_get_info(const rt_multi *multi, rt_multi_info *out);
 int rt_multi_destroy(rt_multi *multi);
+
+/* The cut (pure arithmetic, no device): ngpu contiguous strips of a W-column image, in GPU order, that minimise the frame
+ * time when GPU 0 only renders and every other GPU renders and sends -- max(R, S) + min(R, S) / chunks for a peer whose
+ * strip takes R to render and S to send (chunks = 1: R + S).  A column costs what its strip cost in the measurement:
+ * kernel_ms[g] spread evenly over columns [measured_bounds[g], measured_bounds[g + 1]); sending one column takes
+ * send_ms_per_column.  out_bounds: ngpu + 1 ints.  The same arithmetic, bit for bit, as balanced_bounds() of
+ * tilecoderaytracer_amd/distributed.py (bench.py's one-process-per-GPU path).  Returns 0, or 1 on bad arguments.
+ * Replaces: `dz = SCREEN_VERTICAL_RESOLUTION / CORE_NUM` (src/RayTracer.cpp:904-912), which assumes equal cost. */
+int rt_balance_strips(int W, int ngpu, const int *measured_bounds, const double *kernel_ms,
+                      double send_ms_per_column, int chunks, int *out_bounds);
+/* column chunks per strip: 1 while a strip's transfer is short next to its kernel, up to `most` where it is as long or
+ * longer: round(4 send_ms / kernel_ms) clamped to [1, most] */
+int rt_suggest_chunks(double kernel_ms, double send_ms, int most);
 
 /* Chunk k of `chunks` column chunks of columns [x0, x1): [*a, *b), about equal widths, inner
  * boundaries a multiple of `align` columns from x0 (trailing chunks may be empty).  Returns 0, or
  * 1 on bad arguments. */
 int rt_chunk_bounds(int x0, int x1, int chunks, int k, int align, int *a, int *b);
 
-/* The partition rt_render_multi uses: strip g of ngpu equal x-strips of ceil(W / ngpu) columns is
+/* The equal partition (what the measurement starts from): strip g of ngpu equal x-strips of ceil(W / ngpu) columns is
  * columns [*x0, *x1) (trailing strips may be short or empty); returns the strip width, which is also
  * the column stride of the strips in the gathered buffer (rank g at g * width: only trailing strips
  * are short, so columns [0, W) are contiguous at its start).  Returns 0 on bad arguments. */
 int rt_strip_bounds(int W, int ngpu, int g, int *x0, int *x1);
 
-/* Diagnostic "counting build" of rt_render (same arithmetic and control flow,
- * plus work counters; slower).  stats[k], k < RT_STATS_COUNT:
- *   0 nearest-hit rays (lanes)        1 shadow rays (lanes)
- *   2 nearest-hit scans (wavefronts)  3 shadow scans (wavefronts)
- *   4 sphere tests issued (wavefronts) 5 plane tests issued (wavefronts)
- *   6 cluster box tests issued (wavefronts)
- *   7 sphere tests the lane itself needed (lanes)
- *   8, 9, 10 shader cycles wavefronts spent in nearest-hit scans, in shadow
- *     scans, and on whole tiles (each wavefront counts its own resident time,
- *     so these are comparable with each other, not with wall time)
- *   11, 12, 13 the same for the winner's collision record, the light loop
- *     (shadow scans included) and the reflection step
- *   14, 15, 16 shadow scans: items left by the bundle cull, leaves some lane
- *     needed, and (summed over scans) the most leaves one lane needed
- *   17, 18, 19, 20 nearest-hit scans (wavefronts) by how many of the 64 lanes traced
- *     a ray: 1-16, 17-32, 33-48, 49-64 (what bounce compaction could merge)
- *   21, 22 nearest-hit scans whose bundle cull was skipped (ray directions of both signs on
- *     every axis), and the cluster box tests issued in them
- *   23, 24 sphere tests of cluster leaves issued in those scans, and in all nearest-hit scans
- * wave_cycles (may be NULL) receives, per wavefront tile in row-major order
- * (tile = tile_row * tiles_x + tile_col), six words {shader cycles the
- * wavefront was resident, sphere tests it issued, box tests it issued, scans
- * it ran, start and end time on the 100 MHz constant clock}, up to
- * n_wave_cycles words.  out_rgb may be NULL.  The reference has no
- * counterpart (its gprof figures are quoted in SURVEY.md section 3.3). */
-#define RT_STATS_COUNT 25
-int rt_render_stats(rt_scene *scene, const rt_camera_desc *cam, int W, int H, int x0, int x1,
-                    int max_depth, float *out_rgb, uint64_t *stats, int n_stats,
-                    uint64_t *wave_cycles, int n_wave_cycles);
-
-
-/* Learn where this scene's launches of ONE shape start handing out their tile rows (speed only).  Renders that shape once with
- * the counting build (about three times a frame's time; no pixels are returned) and keeps, per macro row (four tile rows), the
- * longest tile and the rows' sums; every later rt_render / rt_render_device with the same W, H, x0, x1, max_depth and tile shape
- * starts its queues a little before the row of the longest tile, sweeping up or down, instead of by the start-row rule
- * ("first_row" -1) -- if that measured faster: the call times the rule's sweep and the two learned ones and keeps a learned one
- * only if it beats the rule by 3 %.  A launch that is short of tiles -- one GPU's strip of a multi-GPU frame --
- * ends waiting for its longest tiles, and which they are is a matter of the scene and the camera (the previous frame knows).
- * The timed frames (about twenty) go into the handle's own buffer (they count in rt_get_timing:
- * rt_reset_timing afterwards).  rt_set_option("learned_order", 0) forgets it; so does learning another shape.
- * Replaces nothing in the reference (its workers pull pixels in index order, src/RayTracer.cpp:956-992). */
-int rt_learn_tile_order(rt_scene *scene, const rt_camera_desc *camera, int W, int H, int x0, int x1, int max_depth);
-/* Diagnostic BUILDS only (make -C tilecoderaytracer_amd/csrc variant NAME=timeline DEFS=-DRT_TIMELINE=1; the product
- * library refuses the option: the few instructions it takes cost the render kernels registers): with option
- * "timeline" = 1 every launch records, per wavefront tile in row-major order
- * (tile = tile_row * tiles_x + tile_col, rt_launch_info's tile shape), four words: {start, end on the GPU's
- * 100 MHz constant clock, workgroup * 16 + wavefront that rendered it, 1 if it was rendered as a HEAVY tile};
- * this copies up to n_words of the last launch's record (waits for the launch). */
-int rt_get_timeline(rt_scene *scene, uint64_t *out, int n_words);
-
 int rt_get_timing(const rt_scene *scene, rt_timing *out);
 int rt_reset_timing(rt_scene *scene);
-int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
-
-/* Tuning knobs (speed only, never results).  key:
- *   "tile_z"        wavefront tile height, 1,2,4,...,64 (width = 64 / height)
- *   "block_threads" 0 = auto, else 64, 128, 192 or 256 (a value beyond the launch bounds of
- *                   the kernel a launch picks -- 320..512 -- is refused by that launch)
- *   "stack"         bounce stack: 0 auto, 1 LDS, 2 HBM
- *   "pairs"         scenes with clustered sphere runs: 0 = every needed leaf is tested for
- *                   the whole wavefront (round 1's route); 1 (default) = the (ray, leaf)
- *                   pairs that the per-lane box tests leave are compacted into full
- *                   wavefront rounds
- *   "tables"        where the kernel reads the scene tables: 1 = LDS (staged once per
- *                   workgroup; at most 160 KiB), 2 = global memory through the L2 (any
- *                   size), 0 = automatic (LDS up to 80 KiB)
- *   "grid_mult"     persistent grid = occupancy x CUs x this; 0 = no persistence
- *   "first_row"     where the tile queues start, thousandths of the image
- *                   height (from there upwards; rows wrap around); -1 = automatic:
- *                   row 0 upwards, or -- scenes with a horizon and clustered sphere
- *                   runs -- from a little above the horizon row downwards (tiles in
- *                   order of decreasing cost)
- *   "cull"          0 = the plain scans of the reference: every object one item in
- *                   Scene index order, no wavefront-level culling, no
- *                   nearest-first early exit, no sphere clustering, no
- *                   axis-aligned route (the slow baseline the fast path is
- *                   checked against, pixel for pixel, in tests/)
- *   "help"          scenes with clustered sphere runs: 1 = a wavefront that has run out
- *                   of tiles stays and tests candidate leaves of its workgroup's long
- *                   shadow scans (a desk in LDS, a shared cursor over the candidates;
- *                   blocking is an OR, so who tests which leaf cannot change a pixel):
- *                   shortens the end of a GPU's strip of a frame; -1 (default) =
- *                   automatic: on for launches of at most three quarters of the image's
- *                   width (a whole frame pays 1 % for the owners' looks at the desk and
- *                   ends well without help); 0 = such wavefronts leave; 2..64 = on, and
- *                   a scan asks for help from this many candidate leaves on (default 8;
- *                   tests use 2)
- *   "heavy"         scenes with clustered sphere runs under a horizon (with "help" on): the tiles
- *                   of the band of tile rows along the horizon line -- each keeps a wavefront
- *                   busy for a millisecond -- are rendered first, one per WORKGROUP (one
- *                   wavefront renders, the others share its shadow scans from the first on);
- *                   -1 (default) = automatic: when the launch renders a strip of at most a
- *                   third of the image's width (one GPU's share on three or more), a band of
- *                   0.25 % of the image height either side of the line; 0 = off; k = always,
- *                   k - 1 tile rows either side
- *   "tile_prio"     a wavefront's priority on its SIMD follows the bounce level of its tile (the
- *                   tiles whose rays go on bouncing are the long ones, and a launch short of tiles
- *                   waits for them): -1 (default) = automatic, for strips of at most three fifths
- *                   of the image's width; 0 = off; 1 = on
- *   "help_spin_limit" the bound of an owner's wait for helpers to leave its desk (default
- *                   2^22 polls); -1 makes every such wait count as timed out: the owner then
- *                   tests the leaves itself (same pixels), its workgroup stops helping, and
- *                   the next rt_render / rt_get_timing returns RT_ERR_HIP once (tests)
- *   "timeline"      diagnostic builds: 1 = launches record per tile when and by whom it was rendered
- *                   (rt_get_timeline); the product library accepts 0 only
- *   "fast"          scenes without clustered runs: 1 (default) = one kind-sorted item list
- *                   with direct test records (FAST tables), 0 = the two item tables
- *   "primary"       FAST tables: 1 (default) = the scan of the camera rays culls by the pixel rectangle
- *                   every item's box projects to (computed per launch from the camera; scenes of up to
- *                   64 items), 0 = by the bundle of rays like every other scan
- *   "tight_planes"  0 = plane items get the (much larger) padding of sphere items
- *   "aa_planes"     0 switches the axis-aligned rectangle route off
- *   "cluster_leaf"  spheres per leaf of a clustered run (default -1 = by the run's length: 16 below 512
- *                   spheres, 20 below 896, 24 below 3 000, else 32; 0 = no clustering) */
-int rt_set_option(rt_scene *scene, const char *key, int value);
 
 int         rt_device_count(int *count);
 int         rt_capi_version(void);

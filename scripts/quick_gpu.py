@@ -9,7 +9,7 @@ if "only" in opts:
     cases = [c for c in cases if c[0] in opts["only"].split(",")]
 for name, S, d in cases:
     r = Renderer(HostScene.named(name))
-    for k in ("tile_z", "block_threads", "cluster_leaf", "grid_mult", "aa_planes", "stack", "first_row", "pairs", "heavy", "help", "fast", "tight_planes", "tables"):
+    for k in ("tile_z", "block_threads", "cluster_leaf", "grid_mult", "aa_planes", "stack", "first_row", "pairs", "heavy", "help", "fast", "tight_planes", "tables", "wide", "help", "tile_prio"):
         if k in opts:
             r.set_option(k, int(opts[k]))
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")

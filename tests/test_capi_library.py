@@ -12,10 +12,18 @@ from tilecoderaytracer_amd import HostScene, RtError, capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "rt_capi.h")).read()
+def declared_functions(header="rt_capi.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"^\s*(?:int|const char \*)\s*(rt_\w+)\s*\(", text, flags=re.M)))
+
+
+DROP_IN = ["rt_balance_strips", "rt_capi_version", "rt_chunk_bounds", "rt_device_count", "rt_get_timing", "rt_last_error",
+           "rt_multi_create", "rt_multi_destroy", "rt_multi_get_info", "rt_multi_render", "rt_multi_set_bounds",
+           "rt_render", "rt_render_device", "rt_render_multi", "rt_reset_timing", "rt_scene_create", "rt_scene_destroy",
+           "rt_strip_bounds", "rt_suggest_chunks"]
+TUNING = ["rt_capi_tuning_version", "rt_get_launch_info", "rt_get_timeline", "rt_learn_tile_order", "rt_multi_set_option",
+          "rt_render_stats", "rt_set_option"]
 
 
 def test_header_declares_the_expected_entry_points():
@@ -25,11 +33,31 @@ def test_header_declares_the_expected_entry_points():
         assert n in names
 
 
+def test_the_two_headers_split_the_abi():
+    """include/rt_capi.h is the drop-in surface (scenes, renders, the multi-GPU partition, timing, errors) and nothing
+    else; options, the counting build, diagnostics and the calibration call are include/rt_capi_tuning.h, which has its
+    own version number.  INTEGRATION.md sections 1-2 (what a maintainer of the reference adds) use the first only."""
+    assert declared_functions("rt_capi.h") == DROP_IN
+    assert declared_functions("rt_capi_tuning.h") == TUNING
+    drop_in_text = open(os.path.join(ROOT, "include", "rt_capi.h")).read()
+    assert "rt_set_option(" not in re.sub(r"/\*.*?\*/", "", drop_in_text, flags=re.S)
+    assert '#include "rt_capi.h"' in open(os.path.join(ROOT, "include", "rt_capi_tuning.h")).read()
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    first_two = integration[integration.index("## 1."):integration.index("## 3.")]
+    assert "rt_capi_tuning.h" not in first_two
+    for name in TUNING:
+        assert name not in first_two, name
+
+
 def test_library_exports_every_declared_symbol():
     lib = capi.load_library()
-    for name in declared_functions():
+    for name in declared_functions("rt_capi.h") + declared_functions("rt_capi_tuning.h"):
         assert getattr(lib, name) is not None, name
-    assert lib.rt_capi_version() == 2
+    assert lib.rt_capi_version() == 3 and lib.rt_capi_tuning_version() == 1
+    for header, macro, fn in (("rt_capi.h", "RT_CAPI_VERSION", lib.rt_capi_version),
+                              ("rt_capi_tuning.h", "RT_CAPI_TUNING_VERSION", lib.rt_capi_tuning_version)):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        assert int(re.search(r"#define %s (\d+)" % macro, text).group(1)) == fn()
 
 
 def test_struct_sizes_match_the_header():
@@ -39,6 +67,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(capi.RtCameraDesc) == 64
     assert C.sizeof(capi.RtTiming) == 40
     assert C.sizeof(capi.RtLaunchInfo) == 24 + 48      # six int32 + kernel[48]
+    assert C.sizeof(capi.RtMultiInfo) == 4 * 3 + 4 * 17 + 8 * 16 + 8 + 8 * 16 + 8
 
 
 def _create(desc):
@@ -153,6 +182,6 @@ def test_library_path_can_be_overridden(monkeypatch, tmp_path):
 
 def test_counting_build_names_match_the_header():
     from tilecoderaytracer_amd import Renderer
-    text = open(os.path.join(ROOT, "include", "rt_capi.h")).read()
+    text = open(os.path.join(ROOT, "include", "rt_capi_tuning.h")).read()
     count = int(re.search(r"#define RT_STATS_COUNT (\d+)", text).group(1))
     assert len(Renderer.STAT_NAMES) == count

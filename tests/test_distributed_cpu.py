@@ -352,3 +352,69 @@ def test_rt_render_multi_strip_arithmetic(oracle):
         image = full.reshape(-1)[: W * H * 3].reshape(W, H, 3)        # the image_bytes copy to the caller
         assert np.array_equal(image.view(np.uint32), want.view(np.uint32)), (W, n)
     assert lib.rt_strip_bounds(0, 2, 0, None, None) == 0 and lib.rt_strip_bounds(8, 2, 2, None, None) == 0
+
+
+def test_c_side_partition_is_the_python_solver_bit_for_bit():
+    """rt_balance_strips / rt_suggest_chunks (csrc/rt_multi.hip: what rt_multi_render(chunks = 0), rt_render_multi and
+    bin/tcrt_raytracer --gpus G cut their strips with) against balanced_bounds / suggest_chunks (what bench.py's
+    one-process-per-GPU path uses): the same bounds, column for column, on measured-looking and adversarial inputs."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    from tilecoderaytracer_amd.distributed import balanced_bounds, equal_bounds, suggest_chunks
+    lib = capi.load_library()
+    rng = np.random.RandomState(11)
+
+    def c_bounds(W, n, measured, kernel_ms, send, chunks):
+        mb = (C.c_int * (n + 1))(*([a for a, _ in measured] + [W]))
+        km = (C.c_double * n)(*kernel_ms)
+        out = (C.c_int * (n + 1))()
+        assert lib.rt_balance_strips(W, n, mb, km, send, chunks, out) == 0
+        return [(out[g], out[g + 1]) for g in range(n)]
+
+    cases = 0
+    for W in (8, 37, 500, 4096, 8192):
+        for n in (1, 2, 3, 4, 8):
+            measured = equal_bounds(W, n)
+            for kind in range(4):
+                if kind == 0:
+                    kernel_ms = [1.0] * n
+                elif kind == 1:
+                    kernel_ms = list(rng.uniform(0.05, 3.0, n))
+                elif kind == 2:
+                    kernel_ms = [0.0 if g % 2 else 2.0 for g in range(n)]                 # strips that cost nothing
+                else:
+                    kernel_ms = [0.18, 0.2, 0.21, 0.25, 0.9, 0.88, 0.3, 0.2][:n]          # a costly middle, like the sphere grids
+                cost = np.zeros(W)
+                for (a, b), k in zip(measured, kernel_ms):
+                    if b > a:
+                        cost[a:b] = max(k, 0.0) / (b - a)
+                for send in (0.0, 0.34 / max(W // n, 1), 3.0 * float(np.mean(kernel_ms)) / max(W // n, 1)):
+                    for chunks in (1, 2, 4, 8):
+                        want = [tuple(int(v) for v in b) for b in balanced_bounds(W, n, cost, send, overlap=False, chunks=chunks)]
+                        got = c_bounds(W, n, measured, kernel_ms, send, chunks)
+                        assert got == want, (W, n, kind, send, chunks, got, want)
+                        assert got[0][0] == 0 and got[-1][1] == W and all(got[g][1] == got[g + 1][0] for g in range(n - 1))
+                        cases += 1
+    assert cases > 500
+    # measured on a partition that is not the equal one (a re-cut of a re-cut)
+    W, n = 4096, 4
+    measured = [(0, 1500), (1500, 2100), (2100, 2500), (2500, 4096)]
+    kernel_ms = [1.0, 1.1, 0.9, 1.05]
+    cost = np.zeros(W)
+    for (a, b), k in zip(measured, kernel_ms):
+        cost[a:b] = k / (b - a)
+    assert c_bounds(W, n, measured, kernel_ms, 1e-4, 2) == [tuple(int(v) for v in b) for b in balanced_bounds(W, n, cost, 1e-4, overlap=False, chunks=2)]
+    # the chunk count, ties of round() included (half to even in both)
+    for k in (0.0, 0.1, 0.2, 0.25, 0.5, 1.0, 1.2, 4.0):
+        for s in (0.0, 0.0625, 0.1, 0.125, 0.3, 0.34, 0.375, 0.5, 0.625, 1.0, 2.5, 10.0):
+            for most in (1, 4, 8):
+                assert lib.rt_suggest_chunks(k, s, most) == suggest_chunks(k, s, most), (k, s, most)
+    # bad arguments
+    mb = (C.c_int * 3)(0, 4, 8)
+    km = (C.c_double * 2)(1.0, 1.0)
+    out = (C.c_int * 3)()
+    assert lib.rt_balance_strips(8, 2, mb, km, 0.0, 1, out) == 0
+    assert lib.rt_balance_strips(0, 2, mb, km, 0.0, 1, out) == 1 and lib.rt_balance_strips(8, 2, None, km, 0.0, 1, out) == 1
+    assert lib.rt_balance_strips(9, 2, mb, km, 0.0, 1, out) == 1                      # the measured strips do not cover the image
+    km[1] = float("nan")
+    assert lib.rt_balance_strips(8, 2, mb, km, 0.0, 1, out) == 1

@@ -383,11 +383,59 @@ def test_multi_handle_renders_frames_in_column_chunks(oracle):
                 capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, chunks, out.ctypes.data))
                 assert_same(out, orc.render(W, H, depth), f"{name} {W}x{H} d{depth} in {chunks} chunks")
             out = np.zeros((8, 8, 3), dtype=np.float32)
-            assert lib.rt_multi_render(m, host.camera, 8, 8, 1, 0, out.ctypes.data) == capi.RT_ERR_INVALID
+            assert lib.rt_multi_render(m, host.camera, 8, 8, 1, -1, out.ctypes.data) == capi.RT_ERR_INVALID
             assert lib.rt_multi_render(m, host.camera, 8, 8, 1, 65, out.ctypes.data) == capi.RT_ERR_INVALID
         finally:
             capi.check(lib.rt_multi_destroy(m))
     assert lib.rt_multi_create(host.desc, 64, C.byref(m)) == capi.RT_ERR_INVALID      # more GPUs than the box has
+
+
+def test_multi_handle_automatic_partition_and_callers_bounds(oracle):
+    """rt_multi_render with chunks = 0 (what rt_render_multi and tcrt_raytracer --gpus use): the strips come from a
+    measurement of the frame shape, made once and reused, or from rt_multi_set_bounds.  On one GPU the cut is the whole
+    image (nothing to balance, nothing to send); what is checked is the path, the bookkeeping rt_multi_get_info reports,
+    and that a frame that FAILS half-way leaves the handle usable (nothing queued, no RCCL group open)."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    lib = capi.load_library()
+    host, orc = HostScene.named("grid9"), oracle.OracleScene.named("grid9")
+    m = C.c_void_p()
+    capi.check(lib.rt_multi_create(host.desc, 1, C.byref(m)))
+    try:
+        info = capi.RtMultiInfo()
+        for W, H, depth in ((96, 40, 3), (96, 40, 3), (50, 30, 2)):                 # the second frame reuses the first one's cut
+            out = np.zeros((W, H, 3), dtype=np.float32)
+            capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+            assert_same(out, orc.render(W, H, depth), f"automatic partition {W}x{H}")
+            capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+            assert info.ngpu == 1 and info.chunks == 1 and info.balanced == 0
+            assert (info.bounds[0], info.bounds[1]) == (0, W) and info.kernel_ms[0] > 0.0 and info.frame_ms >= info.kernel_ms[0]
+        # a caller's own cut: one strip [0, W) in 5 chunks; a cut for another width is ignored for this one
+        W, H, depth = 96, 40, 3
+        bounds = (C.c_int * 2)(0, W)
+        capi.check(lib.rt_multi_set_bounds(m, W, bounds, 5))
+        out = np.zeros((W, H, 3), dtype=np.float32)
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+        assert_same(out, orc.render(W, H, depth), "caller's bounds")
+        capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+        assert info.chunks == 5
+        bad = (C.c_int * 2)(0, W - 1)
+        assert lib.rt_multi_set_bounds(m, W, bad, 1) == capi.RT_ERR_INVALID
+        bad = (C.c_int * 2)(3, W)
+        assert lib.rt_multi_set_bounds(m, W, bad, 1) == capi.RT_ERR_INVALID
+        assert lib.rt_multi_set_bounds(m, W, bounds, 0) == capi.RT_ERR_INVALID
+        capi.check(lib.rt_multi_set_bounds(m, 0, None, 0))                            # forget it
+        # a frame that fails after the handle has queued work before (a negative depth is refused by the first launch)
+        assert lib.rt_multi_render(m, host.camera, W, H, -1, 3, out.ctypes.data) == capi.RT_ERR_INVALID
+        assert b"max_depth" in lib.rt_last_error()
+        assert lib.rt_multi_render(m, host.camera, W, H, -1, 0, out.ctypes.data) == capi.RT_ERR_INVALID
+        out[:] = 0
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+        assert_same(out, orc.render(W, H, depth), "after two failed frames")
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 4, out.ctypes.data))
+        assert_same(out, orc.render(W, H, depth), "after two failed frames, chunked")
+    finally:
+        capi.check(lib.rt_multi_destroy(m))
 
 
 def test_host_executable_writes_the_reference_log(oracle, tmp_path):

@@ -1,6 +1,7 @@
-"""ctypes bindings for the drop-in boundary, include/rt_capi.h.
+"""ctypes bindings for the drop-in boundary, include/rt_capi.h, and for the
+speed-only options and diagnostics of include/rt_capi_tuning.h.
 
-Struct layouts below must match the header field for field.
+Struct layouts below must match the headers field for field.
 """
 import ctypes as C
 import os
@@ -66,6 +67,20 @@ class RtLaunchInfo(C.Structure):
     ]
 
 
+RT_MULTI_MAX_GPUS = 16
+
+
+class RtMultiInfo(C.Structure):
+    _fields_ = [
+        ("ngpu", C.c_int32), ("chunks", C.c_int32), ("balanced", C.c_int32),
+        ("bounds", C.c_int32 * (RT_MULTI_MAX_GPUS + 1)),
+        ("kernel_ms", C.c_double * RT_MULTI_MAX_GPUS),
+        ("frame_ms", C.c_double),
+        ("measured_kernel_ms", C.c_double * RT_MULTI_MAX_GPUS),
+        ("measured_gather_ms", C.c_double),
+    ]
+
+
 class RtError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"rt_capi error {code}: {message}")
@@ -107,6 +122,11 @@ def load_library():
     lib.rt_multi_create.argtypes = [C.POINTER(RtSceneDesc), i, C.POINTER(vp)]
     lib.rt_multi_render.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, vp]
     lib.rt_multi_set_option.argtypes = [vp, C.c_char_p, i]
+    lib.rt_multi_set_bounds.argtypes = [vp, i, C.POINTER(i), i]
+    lib.rt_multi_get_info.argtypes = [vp, C.POINTER(RtMultiInfo)]
+    lib.rt_balance_strips.argtypes = [i, i, C.POINTER(i), C.POINTER(C.c_double), C.c_double, i, C.POINTER(i)]
+    lib.rt_suggest_chunks.argtypes = [C.c_double, C.c_double, i]
+    lib.rt_capi_tuning_version.restype = i
     lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_render_stats.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, C.POINTER(C.c_uint64), i, vp, i]
     lib.rt_learn_tile_order.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i]
@@ -119,7 +139,8 @@ def load_library():
     for name in ("rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render",
                  "rt_render_device", "rt_render_multi", "rt_render_stats", "rt_learn_tile_order", "rt_get_timing", "rt_reset_timing",
                  "rt_get_launch_info", "rt_set_option", "rt_chunk_bounds", "rt_multi_create", "rt_multi_render",
-                 "rt_multi_set_option", "rt_multi_destroy"):
+                 "rt_multi_set_option", "rt_multi_destroy", "rt_multi_set_bounds", "rt_multi_get_info", "rt_balance_strips",
+                 "rt_suggest_chunks"):
         getattr(lib, name).restype = i
     _lib = lib
     return lib

@@ -11,7 +11,7 @@
  * reference fixes those at compile time; here they are run-time options:
  *   --width W --height H --depth D
  *   --scene 1 | 2 | grid:N | grid:N:noshadow
- *   --gpus G            x-strips over G GPUs, gathered with RCCL
+ *   --gpus G            x-strips over G GPUs, cut by measured cost, sent to GPU 0 with RCCL
  *   --out FILE          (default raytracer_screen.txt)   --no-txt
  */
 #include <chrono>
@@ -103,7 +103,22 @@ int main(int argc, char **argv) {
         }
         rt_scene_destroy(scene);
     } else {
-        rc = rt_render_multi(&flat.desc, &cam, W, H, depth, gpus, pixels.data());
+        /* rt_render_multi() with the handle kept long enough to say how the image was cut: strips by measured cost, each
+         * sent to GPU 0 in column chunks while the next chunk is rendered (rt_multi_render, chunks = 0) */
+        rt_multi *multi = nullptr;
+        rc = rt_multi_create(&flat.desc, gpus, &multi);
+        if (rc == RT_OK) rc = rt_multi_render(multi, &cam, W, H, depth, 0, pixels.data());
+        rt_multi_info info;
+        if (rc == RT_OK && rt_multi_get_info(multi, &info) == RT_OK) {
+            std::printf("Partition: %d x-strips of", info.ngpu);
+            for (int g = 0; g < info.ngpu; ++g) {
+                std::printf("%s%d", g ? "/" : " ", info.bounds[g + 1] - info.bounds[g]);
+                if (info.kernel_ms[g] > kernel_ms) kernel_ms = info.kernel_ms[g];
+            }
+            std::printf(" columns (%s), %d column chunk(s) per strip; frame %f ms\n",
+                        info.balanced ? "cut by measured cost" : "equal", info.chunks, info.frame_ms);
+        }
+        rt_multi_destroy(multi);
     }
     if (rc != RT_OK) {
         std::fprintf(stderr, "render failed (%d): %s\n", rc, rt_last_error());
@@ -120,8 +135,8 @@ int main(int argc, char **argv) {
     std::printf("Total_Time (s) (Time.h)    : %f\n", run_time_s);
     std::printf("Render call (s)            : %f\n", render_s);
     if (kernel_ms > 0.0)
-        std::printf("Render kernel (ms)         : %f  (%.1f Mrays/s)\n", kernel_ms,
-                    (double)W * (double)H / (kernel_ms * 1e3));
+        std::printf("Render kernel (ms)         : %f  (%.1f Mrays/s)%s\n", kernel_ms,
+                    (double)W * (double)H / (kernel_ms * 1e3), gpus > 1 ? "  [the GPU whose kernels took longest]" : "");
     std::printf("AverageRoundTime (us/pixel): %f\n", run_time_us / ((double)W * (double)H));
 
     if (write_txt) {

@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/rt_capi.h"
+#include "../../include/rt_capi_tuning.h"
 #include "rt_tables.h"
 
 #define RT_DECLARE_KERNEL(name)                                                                                   \
@@ -90,6 +90,7 @@ struct rt_scene {
     int timeline_opt = 0;                     /* diagnostic: every launch records per tile when and by whom it was rendered */
     unsigned long long *d_timeline = nullptr;
     size_t timeline_words = 0, timeline_valid = 0;
+    int wide_opt = -1;            /* experiments: which clustered-scene kernel (-1 automatic, 0 the 80-register one, 1 the 96-register one) */
     int pairs_opt = 1;            /* scenes with clustered runs: the kernel that compacts (ray, leaf) pairs (0: the plain kernel) */
     int tables_opt = 0;           /* where the kernel reads the tables: 0 = automatic, 1 = LDS, 2 = global memory (any size) */
     int grid_mult = 1;            /* grid = occupancy * CUs * this; 0 = one workgroup per 4 tiles (no persistence) */
@@ -1076,7 +1077,8 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
             }
         }
     }
-    const bool clusters_wide = (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
+    const bool clusters_wide = s->wide_opt >= 0 ? s->wide_opt != 0
+                                                : (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
     const bool fast_tables = s->base.n_fast_items > 0;
     struct Kernel { const void *fn; const char *name; };
 #define RT_KERNEL(k) Kernel{(const void *)k, #k}
@@ -1161,6 +1163,8 @@ extern "C" {
 int rt_internal_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 
 int rt_capi_version(void) { return RT_CAPI_VERSION; }
+
+int rt_capi_tuning_version(void) { return RT_CAPI_TUNING_VERSION; }
 
 const char *rt_last_error(void) { return g_last_error.c_str(); }
 
@@ -1467,6 +1471,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         s->help_spin_opt = value;
         return RT_OK;
     }
+    if (!std::strcmp(key, "wide")) { s->wide_opt = value < 0 ? -1 : (value != 0); return RT_OK; }
     if (!std::strcmp(key, "pairs")) {
         s->pairs_opt = value != 0;
         return RT_OK;

@@ -40,7 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/rt_capi.h"      /* RT_STATS_COUNT: the counting build's counters are part of the ABI */
+#include "../../include/rt_capi_tuning.h"      /* RT_STATS_COUNT: the counting build's counters are part of the (tuning) ABI */
 #include "rt_tables.h"
 
 #pragma clang fp contract(off)
@@ -566,7 +566,7 @@ __device__ __forceinline__ void bound_multipliers(const float dmin, const float 
  * would idle.  Nobody ever waits for a helper to ARRIVE; the owner's wait for helpers to LEAVE is bounded by
  * one leaf's tests (and by RT_HELP_SPIN_LIMIT, after which the kernel gives up helping for good). */
 enum { RT_DESK_FREE = 0, RT_DESK_FILLING = 1, RT_DESK_OPEN = 2, RT_DESK_CLOSING = 3 };
-static_assert(ST_COUNT == RT_STATS_COUNT, "RT_STATS_COUNT in include/rt_capi.h must equal ST_COUNT");
+static_assert(ST_COUNT == RT_STATS_COUNT, "RT_STATS_COUNT in include/rt_capi_tuning.h must equal ST_COUNT");
 
 /* the desk's words are read and written with workgroup-scope atomics on the LDS pointer itself (ds_read / ds_write that
  * the compiler may neither cache nor move); a volatile generic pointer turned them into flat loads */

@@ -5,17 +5,27 @@
  * across the GPUs of one node from a single process.
  *
  * Partition: contiguous x-strips.  The framebuffer is x-major
- * (pixels[x][z], src/RayTracer.h:44), so strip g is one contiguous block and
- * rank order equals memory order: ncclGather(root 0) drops every strip in
- * place, no repacking.  dx/dz are computed from the global x and W, H, so the
- * gathered image is bit-identical to a single-GPU render.
+ * (pixels[x][z], src/RayTracer.h:44), so strip g is one contiguous block of the
+ * image and its columns land in place on device 0 (ncclSend on the strip's GPU,
+ * ncclRecv on device 0, point to point over the GPU's own xGMI link), no
+ * repacking.  dx/dz are computed from the global x and W, H, so the gathered
+ * image is bit-identical to a single-GPU render.
+ *
+ * The strips are cut by MEASURED cost (rt_multi_render with chunks = 0, which is
+ * what rt_render_multi and bin/tcrt_raytracer --gpus G use): a warm-up frame on
+ * equal strips gives every GPU's kernel time and the time the transfers take on
+ * their own; device 0, which receives and sends nothing, then gets as many
+ * columns as it renders in the time a peer needs to render AND ship its own
+ * (rt_balance_strips: the arithmetic of tilecoderaytracer_amd/distributed.py's
+ * balanced_bounds, which bench.py's one-process-per-GPU path uses).
  *
  * Within a frame every strip is rendered and sent in column CHUNKS: chunk k
  * travels to device 0 on the device's communication stream while chunk k+1 is
  * rendered on its compute stream -- the reference's ranks, too, write their
  * pixels into the shared image while they render (src/RayTracer.cpp:904-923,
- * 1188-1193); there is no serial "then gather" phase.  rt_multi_create() keeps
- * the scenes, streams, buffers and the communicator across frames.
+ * 1188-1193); there is no serial "then gather" phase.  How many chunks follows
+ * from the same measurement (rt_suggest_chunks).  rt_multi_create() keeps the
+ * scenes, streams, buffers and the communicator across frames.
  *
  * RCCL is bound lazily (dlopen of librccl.so) so that the single-GPU entry
  * points carry no RCCL dependency; per-process multi-GPU (bench.py, one rank
@@ -24,11 +34,15 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
-#include "../../include/rt_capi.h"
+#include "../../include/rt_capi_tuning.h"
 
 namespace {
 
@@ -94,36 +108,274 @@ extern "C" int rt_chunk_bounds(int x0, int x1, int chunks, int k, int align, int
     return 0;
 }
 
+/* ---- the partition's arithmetic: pure functions, the same on every host (tests compare them with distributed.py) ---- */
+
+extern "C" int rt_suggest_chunks(double kernel_ms, double send_ms, int most) {
+    if (most < 1) most = 1;
+    if (!(kernel_ms > 0.0)) return send_ms > 0.0 ? most : 1;
+    const double k = std::nearbyint(4.0 * send_ms / kernel_ms);           /* half to even, like Python's round() */
+    return (int)std::min((double)most, std::max(1.0, k));
+}
+
+extern "C" int rt_balance_strips(int W, int ngpu, const int *measured_bounds, const double *kernel_ms,
+                                 double send_ms_per_column, int chunks, int *out_bounds) {
+    if (W <= 0 || ngpu <= 0 || !measured_bounds || !kernel_ms || !out_bounds) return 1;
+    if (measured_bounds[0] != 0 || measured_bounds[ngpu] != W) return 1;
+    for (int g = 0; g < ngpu; ++g)
+        if (measured_bounds[g] > measured_bounds[g + 1] || !(kernel_ms[g] == kernel_ms[g])) return 1;
+    /* a column costs what its strip took, spread evenly (prefix sums, accumulated in column order) */
+    std::vector<double> prefix((size_t)W + 1, 0.0);
+    for (int g = 0; g < ngpu; ++g) {
+        const int a = measured_bounds[g], b = measured_bounds[g + 1];
+        if (b <= a) continue;
+        const double per_column = std::max(kernel_ms[g], 0.0) / (double)(b - a);
+        for (int x = a; x < b; ++x) prefix[(size_t)x + 1] = per_column;
+    }
+    for (int x = 0; x < W; ++x) prefix[(size_t)x + 1] = prefix[(size_t)x] + prefix[(size_t)x + 1];
+    const double g_send = std::max(send_ms_per_column, 0.0);
+    const int K = std::max(chunks, 1);
+    /* the time GPU r needs for columns [x, x1): device 0 renders only; a peer renders and sends, chunk k on its way while
+     * chunk k + 1 is rendered, so only the first chunk of the slower activity is not covered by the other */
+    auto rank_time = [&](int r, int x, int x1) {
+        const double render = prefix[(size_t)x1] - prefix[(size_t)x];
+        if (r == 0 || g_send <= 0.0) return render;
+        const double send = g_send * (double)(x1 - x);
+        if (K <= 1) return render + send;
+        return std::max(render, send) + std::min(render, send) / (double)K;
+    };
+    /* greedy fill under a time limit, bisection on the limit */
+    auto fill = [&](double limit, int *bounds) {
+        int x = 0;
+        for (int r = 0; r < ngpu; ++r) {
+            int lo = x, hi = W;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) / 2;
+                if (rank_time(r, x, mid) <= limit) lo = mid; else hi = mid - 1;
+            }
+            bounds[r] = x;
+            x = lo;
+        }
+        bounds[ngpu] = x;
+        return x;
+    };
+    std::vector<int> trial((size_t)ngpu + 1);
+    double lo = 0.0, hi = prefix[(size_t)W] + g_send * (double)W + 1e-9;
+    for (int it = 0; it < 60; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (fill(mid, trial.data()) >= W) hi = mid; else lo = mid;
+    }
+    (void)fill(hi, out_bounds);
+    out_bounds[ngpu] = W;                                  /* numerical corner: the rest goes to the last GPU */
+    return 0;
+}
+
 /* the multi-GPU handle: everything that survives from frame to frame */
 struct rt_multi {
     int ngpu = 0;
     std::vector<rt_scene *> scenes;
     std::vector<hipStream_t> compute, comm;          /* per device: the render kernels' stream and the transfers' */
     std::vector<std::vector<hipEvent_t>> rendered;   /* per device, per chunk: that chunk's kernel is done */
-    std::vector<void *> d_strip;                     /* per device g >= 1: its strip, strip_floats floats */
+    std::vector<void *> d_strip;                     /* per device g >= 1: its strip */
     std::vector<size_t> strip_bytes;
     std::vector<ncclComm_t> comms;
     void *d_full = nullptr;                          /* device 0: the whole image; device 0 renders its strip in place */
     size_t full_bytes = 0;
     Rccl rccl;
+    /* the partition in use: ngpu + 1 column bounds for images `bounds_W` wide (empty, or another width: equal strips) */
+    std::vector<int> bounds;
+    int bounds_W = 0, bounds_chunks = 1;
+    bool bounds_explicit = false;                    /* rt_multi_set_bounds: never re-measured */
+    /* what the automatic partition was measured for */
+    bool have_key = false;
+    int key[3] = {0, 0, 0};                          /* W, H, max_depth */
+    rt_camera_desc key_cam{};
+    bool broken = false;                             /* an RCCL call failed mid-frame: the communicator's state is unknown */
+    rt_multi_info info{};
 };
 
 namespace {
 
 int multi_fail(int code, const std::string &msg) { return rt_internal_set_error(code, msg.c_str()); }
 
+constexpr int kMaxChunks = 64;
+constexpr int kAlign = 16;          /* chunk boundaries fall on multiples of 16 columns from the strip's first (the widest wavefront tile) */
+
+void strip_of(const rt_multi *m, int W, int g, int *x0, int *x1) {
+    if (!m->bounds.empty() && m->bounds_W == W) { *x0 = m->bounds[(size_t)g]; *x1 = m->bounds[(size_t)g + 1]; return; }
+    (void)rt_strip_bounds(W, m->ngpu, g, x0, x1);
+}
+
+/* after a failure somewhere in a frame: nothing of it may still be queued when the caller gets the handle back */
+void drain_all(rt_multi *m) {
+    for (int g = 0; g < m->ngpu; ++g) {
+        if (hipSetDevice(g) != hipSuccess) continue;
+        if (m->compute[(size_t)g]) (void)hipStreamSynchronize(m->compute[(size_t)g]);
+        if (m->comm[(size_t)g]) (void)hipStreamSynchronize(m->comm[(size_t)g]);
+    }
+}
+
+/* One frame on the partition in use: every GPU renders its strip in `chunks` column chunks (device 0 straight into the image)
+ * and -- transfers -- chunk k goes to device 0 behind its kernel while chunk k + 1 is rendered; returns when everything is on
+ * device 0.  render = false: the transfers alone (the strips' columns as they are).  Any failure leaves no work queued and
+ * no RCCL group open. */
+int multi_frame(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_depth, int chunks, bool render, bool transfers) {
+    const int ngpu = m->ngpu;
+    const size_t column_floats = (size_t)H * 3;
+    bool group_open = false;
+    auto body = [&]() -> int {
+#define HIP_STEP(expr)                                                                 \
+        do {                                                                           \
+            hipError_t e_ = (expr);                                                    \
+            if (e_ != hipSuccess) return multi_fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        } while (0)
+#define NCCL_STEP(expr)                                                                \
+        do {                                                                           \
+            ncclResult_t r_ = (expr);                                                  \
+            if (r_ != 0) { m->broken = true; return multi_fail(RT_ERR_RCCL, std::string(#expr) + ": " + m->rccl.GetErrorString(r_)); } \
+        } while (0)
+        for (int k = 0; k < chunks; ++k) {
+            for (int g = 0; g < ngpu && render; ++g) {
+                int x0 = 0, x1 = 0, a = 0, b = 0;
+                strip_of(m, W, g, &x0, &x1);
+                (void)rt_chunk_bounds(x0, x1, chunks, k, kAlign, &a, &b);
+                float *dst = g == 0 ? static_cast<float *>(m->d_full) + (size_t)a * column_floats
+                                    : static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats;
+                int rc = rt_render_device(m->scenes[(size_t)g], cam, W, H, a, b, max_depth, dst, m->compute[(size_t)g]);
+                if (rc) return rc;
+                if (g == 0 || !transfers) continue;           /* device 0 sends nothing: its receipts wait for no kernel of its own */
+                HIP_STEP(hipSetDevice(g));
+                HIP_STEP(hipEventRecord(m->rendered[(size_t)g][(size_t)k], m->compute[(size_t)g]));
+                HIP_STEP(hipStreamWaitEvent(m->comm[(size_t)g], m->rendered[(size_t)g][(size_t)k], 0));
+            }
+            if (ngpu > 1 && transfers) {
+                NCCL_STEP(m->rccl.GroupStart());
+                group_open = true;
+                for (int g = 1; g < ngpu; ++g) {
+                    int x0 = 0, x1 = 0, a = 0, b = 0;
+                    strip_of(m, W, g, &x0, &x1);
+                    (void)rt_chunk_bounds(x0, x1, chunks, k, kAlign, &a, &b);
+                    if (b <= a) continue;
+                    const size_t count = (size_t)(b - a) * column_floats;
+                    NCCL_STEP(m->rccl.Send(static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats, count, kNcclFloat, 0,
+                                           m->comms[(size_t)g], m->comm[(size_t)g]));
+                    NCCL_STEP(m->rccl.Recv(static_cast<float *>(m->d_full) + (size_t)a * column_floats, count, kNcclFloat, g,
+                                           m->comms[0], m->comm[0]));
+                }
+                group_open = false;
+                NCCL_STEP(m->rccl.GroupEnd());
+            }
+        }
+        for (int g = 0; g < ngpu; ++g) {
+            HIP_STEP(hipSetDevice(g));
+            HIP_STEP(hipStreamSynchronize(m->compute[(size_t)g]));
+            HIP_STEP(hipStreamSynchronize(m->comm[(size_t)g]));
+        }
+        return RT_OK;
+#undef HIP_STEP
+#undef NCCL_STEP
+    };
+    const int rc = body();
+    if (rc != RT_OK) {
+        const std::string why = rt_last_error();             /* (the clean-up below must not replace the message) */
+        if (group_open) (void)m->rccl.GroupEnd();
+        drain_all(m);
+        return multi_fail(rc, why);
+    }
+    return RT_OK;
+}
+
 #define HIP_OR_FAIL(expr)                                                             \
     do {                                                                              \
         hipError_t e_ = (expr);                                                       \
         if (e_ != hipSuccess) return multi_fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
-#define NCCL_OR_FAIL(m, expr)                                                         \
-    do {                                                                              \
-        ncclResult_t r_ = (expr);                                                     \
-        if (r_ != 0) return multi_fail(RT_ERR_RCCL, std::string(#expr) + ": " + (m)->rccl.GetErrorString(r_)); \
-    } while (0)
 
-constexpr int kMaxChunks = 64;
+/* device memory and events for frames of this shape on the partition in use */
+int multi_reserve(rt_multi *m, int W, int H, int chunks) {
+    const size_t column_floats = (size_t)H * 3;
+    const size_t image_bytes = (size_t)W * column_floats * sizeof(float);
+    HIP_OR_FAIL(hipSetDevice(0));
+    if (image_bytes > m->full_bytes) {
+        if (m->d_full) { HIP_OR_FAIL(hipFree(m->d_full)); m->d_full = nullptr; m->full_bytes = 0; }
+        HIP_OR_FAIL(hipMalloc(&m->d_full, image_bytes));
+        m->full_bytes = image_bytes;
+    }
+    for (int g = 0; g < m->ngpu; ++g) {
+        HIP_OR_FAIL(hipSetDevice(g));
+        int x0 = 0, x1 = 0;
+        strip_of(m, W, g, &x0, &x1);
+        const size_t need = (size_t)std::max(x1 - x0, 1) * column_floats * sizeof(float);
+        if (g > 0 && need > m->strip_bytes[(size_t)g]) {
+            if (m->d_strip[(size_t)g]) { HIP_OR_FAIL(hipFree(m->d_strip[(size_t)g])); m->d_strip[(size_t)g] = nullptr; m->strip_bytes[(size_t)g] = 0; }
+            HIP_OR_FAIL(hipMalloc(&m->d_strip[(size_t)g], need));
+            m->strip_bytes[(size_t)g] = need;
+        }
+        while ((int)m->rendered[(size_t)g].size() < chunks) {
+            hipEvent_t e;
+            HIP_OR_FAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->rendered[(size_t)g].push_back(e);
+        }
+    }
+    return RT_OK;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+/* The measured-cost partition for frames of this shape: one frame on equal strips to warm everything up (code objects, the
+ * links' first use), then the kernels alone (every GPU's time for its equal strip) and the transfers alone (the time the
+ * strips need to reach device 0, all peers at once, each over its own link); rt_suggest_chunks and rt_balance_strips turn that
+ * into the chunk count and the strips.  What tilecoderaytracer_amd/distributed.py's measure_and_balance does for bench.py. */
+int multi_balance(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_depth) {
+    const int ngpu = m->ngpu;
+    m->bounds.clear();
+    m->bounds_chunks = 1;
+    m->have_key = false;
+    m->info.balanced = 0;
+    std::vector<int> equal((size_t)ngpu + 1, W);
+    for (int g = 0; g < ngpu; ++g) { int a, b; (void)rt_strip_bounds(W, ngpu, g, &a, &b); equal[(size_t)g] = a; }
+    std::vector<double> kernel_ms((size_t)ngpu, 0.0);
+    double gather_ms = 0.0;
+    int chunks = 1;
+    std::vector<int> cut = equal;
+    if (ngpu > 1) {
+        int rc = multi_reserve(m, W, H, 1);
+        if (rc) return rc;
+        rc = multi_frame(m, cam, W, H, max_depth, 1, true, true);
+        if (rc) return rc;
+        for (int g = 0; g < ngpu; ++g) { rc = rt_reset_timing(m->scenes[(size_t)g]); if (rc) return rc; }
+        rc = multi_frame(m, cam, W, H, max_depth, 1, true, false);
+        if (rc) return rc;
+        for (int g = 0; g < ngpu; ++g) {
+            rt_timing tm;
+            rc = rt_get_timing(m->scenes[(size_t)g], &tm);
+            if (rc) return rc;
+            kernel_ms[(size_t)g] = tm.sum_kernel_ms;
+        }
+        const double t0 = now_ms();
+        rc = multi_frame(m, cam, W, H, max_depth, 1, false, true);
+        if (rc) return rc;
+        gather_ms = now_ms() - t0;
+        double mean = 0.0;
+        for (double k : kernel_ms) mean += k;
+        mean /= (double)ngpu;
+        chunks = rt_suggest_chunks(mean, gather_ms, 8);
+        const double per_column = gather_ms / (double)std::max(equal[1] - equal[0], 1);
+        if (rt_balance_strips(W, ngpu, equal.data(), kernel_ms.data(), per_column, chunks, cut.data()))
+            return multi_fail(RT_ERR_INVALID, "rt_balance_strips refused the measured times");
+    }
+    m->bounds = cut;
+    m->bounds_W = W;
+    m->bounds_chunks = chunks;
+    m->have_key = true;
+    m->key[0] = W; m->key[1] = H; m->key[2] = max_depth;
+    m->key_cam = *cam;
+    m->info.balanced = ngpu > 1 ? 1 : 0;
+    m->info.measured_gather_ms = gather_ms;
+    for (int g = 0; g < ngpu && g < RT_MULTI_MAX_GPUS; ++g) m->info.measured_kernel_ms[g] = kernel_ms[(size_t)g];
+    return RT_OK;
+}
 
 } // namespace
 
@@ -149,6 +401,7 @@ extern "C" int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **o
     if (!desc || !out) return multi_fail(RT_ERR_INVALID, "desc/out is NULL");
     *out = nullptr;
     if (ngpu <= 0) return multi_fail(RT_ERR_INVALID, "ngpu must be positive");
+    if (ngpu > RT_MULTI_MAX_GPUS) return multi_fail(RT_ERR_INVALID, "ngpu exceeds RT_MULTI_MAX_GPUS");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return multi_fail(RT_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
@@ -163,6 +416,7 @@ extern "C" int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **o
     m->d_strip.assign((size_t)ngpu, nullptr);
     m->strip_bytes.assign((size_t)ngpu, 0);
     m->comms.assign((size_t)ngpu, nullptr);
+    m->info.ngpu = ngpu;
     auto bail = [&](int rc) { rt_multi_destroy(m); return rc; };
     for (int g = 0; g < ngpu; ++g) {
         int rc = rt_scene_create(desc, g, &m->scenes[(size_t)g]);
@@ -193,80 +447,80 @@ extern "C" int rt_multi_set_option(rt_multi *m, const char *key, int value) {
     return RT_OK;
 }
 
+extern "C" int rt_multi_set_bounds(rt_multi *m, int W, const int *bounds, int chunks) {
+    if (!m) return multi_fail(RT_ERR_INVALID, "handle is NULL");
+    if (!bounds) {                                     /* back to equal strips / the automatic partition */
+        m->bounds.clear();
+        m->bounds_explicit = false;
+        m->have_key = false;
+        m->bounds_chunks = 1;
+        return RT_OK;
+    }
+    if (W <= 0 || chunks < 1 || chunks > kMaxChunks) return multi_fail(RT_ERR_INVALID, "need W > 0 and chunks in [1, 64]");
+    if (bounds[0] != 0 || bounds[m->ngpu] != W) return multi_fail(RT_ERR_INVALID, "the strips must cover [0, W)");
+    for (int g = 0; g < m->ngpu; ++g)
+        if (bounds[g] > bounds[g + 1]) return multi_fail(RT_ERR_INVALID, "the strips must be in GPU order");
+    m->bounds.assign(bounds, bounds + m->ngpu + 1);
+    m->bounds_W = W;
+    m->bounds_chunks = chunks;
+    m->bounds_explicit = true;
+    m->have_key = false;
+    return RT_OK;
+}
+
+extern "C" int rt_multi_get_info(const rt_multi *m, rt_multi_info *out) {
+    if (!m || !out) return multi_fail(RT_ERR_INVALID, "handle/out is NULL");
+    *out = m->info;
+    return RT_OK;
+}
+
 extern "C" int rt_multi_render(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_depth, int chunks, float *out_rgb) {
     if (!m || !cam || !out_rgb) return multi_fail(RT_ERR_INVALID, "handle/cam/out_rgb is NULL");
     if (W <= 0 || H <= 0) return multi_fail(RT_ERR_INVALID, "W and H must be positive");
-    if (chunks <= 0 || chunks > kMaxChunks) return multi_fail(RT_ERR_INVALID, "chunks must be in [1, 64]");
+    if (chunks < 0 || chunks > kMaxChunks) return multi_fail(RT_ERR_INVALID, "chunks must be in [0, 64] (0: automatic)");
+    if (m->broken)
+        return multi_fail(RT_ERR_RCCL, "an RCCL call failed in an earlier frame of this handle: destroy it and create another");
     const int ngpu = m->ngpu;
-    /* equal strips of ceil(W / ngpu) columns; trailing strips may be short or empty */
-    const int strip = rt_strip_bounds(W, ngpu, 0, nullptr, nullptr);
-    const size_t column_floats = (size_t)H * 3;
-    const size_t image_bytes = (size_t)W * column_floats * sizeof(float);
-    HIP_OR_FAIL(hipSetDevice(0));
-    if (image_bytes > m->full_bytes) {
-        if (m->d_full) { HIP_OR_FAIL(hipFree(m->d_full)); m->d_full = nullptr; m->full_bytes = 0; }
-        HIP_OR_FAIL(hipMalloc(&m->d_full, image_bytes));
-        m->full_bytes = image_bytes;
-    }
-    for (int g = 0; g < ngpu; ++g) {
-        HIP_OR_FAIL(hipSetDevice(g));
-        const size_t need = (size_t)strip * column_floats * sizeof(float);
-        if (g > 0 && need > m->strip_bytes[(size_t)g]) {
-            if (m->d_strip[(size_t)g]) { HIP_OR_FAIL(hipFree(m->d_strip[(size_t)g])); m->d_strip[(size_t)g] = nullptr; m->strip_bytes[(size_t)g] = 0; }
-            HIP_OR_FAIL(hipMalloc(&m->d_strip[(size_t)g], need));
-            m->strip_bytes[(size_t)g] = need;
-        }
-        while ((int)m->rendered[(size_t)g].size() < chunks) {
-            hipEvent_t e;
-            HIP_OR_FAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            m->rendered[(size_t)g].push_back(e);
-        }
-    }
-    /* chunk boundaries fall on multiples of 16 columns from the strip's first (the widest wavefront tile) */
-    const int align = 16;
-    for (int k = 0; k < chunks; ++k) {
-        /* every GPU renders chunk k of its strip (device 0 straight into the image) ... */
-        for (int g = 0; g < ngpu; ++g) {
-            int x0 = 0, x1 = 0, a = 0, b = 0;
-            (void)rt_strip_bounds(W, ngpu, g, &x0, &x1);
-            (void)rt_chunk_bounds(x0, x1, chunks, k, align, &a, &b);
-            float *dst = g == 0 ? static_cast<float *>(m->d_full) + (size_t)a * column_floats
-                                : static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats;
-            int rc = rt_render_device(m->scenes[(size_t)g], cam, W, H, a, b, max_depth, dst, m->compute[(size_t)g]);
-            if (rc) return rc;
-            HIP_OR_FAIL(hipSetDevice(g));
-            HIP_OR_FAIL(hipEventRecord(m->rendered[(size_t)g][(size_t)k], m->compute[(size_t)g]));
-            HIP_OR_FAIL(hipStreamWaitEvent(m->comm[(size_t)g], m->rendered[(size_t)g][(size_t)k], 0));
-        }
-        /* ... and chunk k goes to device 0 over xGMI, behind its kernel, while chunk k + 1 is rendered */
-        if (ngpu > 1) {
-            NCCL_OR_FAIL(m, m->rccl.GroupStart());
-            for (int g = 1; g < ngpu; ++g) {
-                int x0 = 0, x1 = 0, a = 0, b = 0;
-                (void)rt_strip_bounds(W, ngpu, g, &x0, &x1);
-                (void)rt_chunk_bounds(x0, x1, chunks, k, align, &a, &b);
-                if (b <= a) continue;
-                const size_t count = (size_t)(b - a) * column_floats;
-                NCCL_OR_FAIL(m, m->rccl.Send(static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats, count, kNcclFloat, 0,
-                                             m->comms[(size_t)g], m->comm[(size_t)g]));
-                NCCL_OR_FAIL(m, m->rccl.Recv(static_cast<float *>(m->d_full) + (size_t)a * column_floats, count, kNcclFloat, g,
-                                             m->comms[0], m->comm[0]));
+    if (chunks == 0) {
+        /* automatic: the strips of rt_multi_set_bounds if there are any, else the measured-cost partition for this shape */
+        if (m->bounds_explicit && m->bounds_W == W) {
+            chunks = m->bounds_chunks;
+        } else {
+            const bool same = m->have_key && m->key[0] == W && m->key[1] == H && m->key[2] == max_depth &&
+                              std::memcmp(&m->key_cam, cam, sizeof(*cam)) == 0;
+            if (!same) {
+                int rc = multi_balance(m, cam, W, H, max_depth);
+                if (rc) return rc;
             }
-            NCCL_OR_FAIL(m, m->rccl.GroupEnd());
+            chunks = m->bounds_chunks;
         }
+    } else if (!m->bounds_explicit && !m->bounds.empty()) {
+        m->bounds.clear();                               /* an explicit chunk count on a measured partition: equal strips, as asked */
+        m->have_key = false;
+        m->info.balanced = 0;
     }
-    for (int g = 0; g < ngpu; ++g) {
-        HIP_OR_FAIL(hipSetDevice(g));
-        HIP_OR_FAIL(hipStreamSynchronize(m->compute[(size_t)g]));
-        HIP_OR_FAIL(hipStreamSynchronize(m->comm[(size_t)g]));
-    }
+    int rc = multi_reserve(m, W, H, chunks);
+    if (rc) return rc;
+    for (int g = 0; g < ngpu; ++g) { rc = rt_reset_timing(m->scenes[(size_t)g]); if (rc) return rc; }
+    const double t0 = now_ms();
+    rc = multi_frame(m, cam, W, H, max_depth, chunks, true, true);
+    if (rc) return rc;
+    m->info.frame_ms = now_ms() - t0;
+    m->info.chunks = chunks;
+    const size_t image_bytes = (size_t)W * (size_t)H * 3 * sizeof(float);
     HIP_OR_FAIL(hipSetDevice(0));
     HIP_OR_FAIL(hipMemcpy(out_rgb, m->d_full, image_bytes, hipMemcpyDeviceToHost));
-    /* what the kernels may have had to tell the host (a HELP wait that timed out: the image is exact, the caller is told) */
+    /* per GPU: its kernels' time in this frame; and what the kernels may have had to tell the host (a HELP wait that timed
+     * out: the image is exact, the caller is told) */
     for (int g = 0; g < ngpu; ++g) {
         rt_timing tm;
-        int rc = rt_get_timing(m->scenes[(size_t)g], &tm);
+        rc = rt_get_timing(m->scenes[(size_t)g], &tm);
         if (rc) return rc;
+        int x0 = 0, x1 = 0;
+        strip_of(m, W, g, &x0, &x1);
+        m->info.bounds[g] = x0;
+        m->info.bounds[g + 1] = x1;
+        m->info.kernel_ms[g] = tm.sum_kernel_ms;
     }
     return RT_OK;
 }
@@ -278,7 +532,7 @@ extern "C" int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *
     rt_multi *m = nullptr;
     int rc = rt_multi_create(desc, ngpu, &m);
     if (rc) return rc;
-    rc = rt_multi_render(m, cam, W, H, max_depth, ngpu > 1 ? 4 : 1, out_rgb);
+    rc = rt_multi_render(m, cam, W, H, max_depth, 0, out_rgb);      /* strips and chunks by measurement */
     rt_multi_destroy(m);
     return rc;
 }
