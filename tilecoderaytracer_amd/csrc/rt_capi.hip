@@ -58,7 +58,7 @@ float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 struct EventPair { hipEvent_t start, stop; bool pending; };
 constexpr int kEventRing = 64;
-constexpr int kCounterWords = (RT_TILE_QUEUES + 1) * RT_QUEUE_STRIDE;   /* 8 queue heads + the HEAVY tiles', own cache lines */
+constexpr int kCounterWords = RT_COUNTER_WORDS;   /* 8 queue heads + the HEAVY tiles', own cache lines */
 
 } // namespace
 
@@ -970,6 +970,9 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     if (!s->d_counters) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters),
                           (size_t)kEventRing * kCounterWords * sizeof(unsigned int)));
+        /* zeroed once; from then on every launch zeroes the block the next launch of this scene will use (rt_kernel.hip) */
+        HIP_TRY(hipMemset(s->d_counters, 0, (size_t)kEventRing * kCounterWords * sizeof(unsigned int)));
+        HIP_TRY(hipDeviceSynchronize());          /* (the launches may be on streams that do not wait for the null stream) */
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1077,8 +1080,9 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
             }
         }
     }
+    /* the 96-register kernel when LDS leaves room for fewer than six wavefronts per SIMD anyway (24 per CU) */
     const bool clusters_wide = s->wide_opt >= 0 ? s->wide_opt != 0
-                                                : (size_t)lds_bytes * 6 > RT_MAX_LDS_BYTES;       /* at most five workgroups per CU */
+                                                : (RT_MAX_LDS_BYTES / (size_t)lds_bytes) * (size_t)(block / 64) < 24;
     const bool fast_tables = s->base.n_fast_items > 0;
     struct Kernel { const void *fn; const char *name; };
 #define RT_KERNEL(k) Kernel{(const void *)k, #k}
@@ -1134,12 +1138,15 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
             s->d_help_bytes = need;
         }
     }
-    const int slot = s->ev_next;
+    /* This launch's block of counters is at zero (the invariant: the block of slot ev_next is, whenever a launch of this scene
+     * starts -- all of them at allocation, and every launch zeroes the next slot's while it runs; launches of one scene are
+     * stream-ordered, above).  The next slot's old launch, 63 launches ago, must be over before this one writes its block. */
+    const int slot = s->ev_next, next_slot = (slot + 1) % kEventRing;
     rc = drain_event(s, slot);            /* ring wrapped: account for the old launch first */
+    if (rc == RT_OK) rc = drain_event(s, next_slot);
     if (rc) return rc;
-    s->ev_next = (s->ev_next + 1) % kEventRing;
     unsigned int *counter = s->d_counters + (size_t)slot * kCounterWords;
-    HIP_TRY(hipMemsetAsync(counter, 0, (size_t)kCounterWords * sizeof(unsigned int), stream));
+    p.next_counters = (uint64_t)(uintptr_t)(s->d_counters + (size_t)next_slot * kCounterWords);
     HIP_TRY(hipEventRecord(s->ev[slot].start, stream));
     const float4 *image_arg = reinterpret_cast<const float4 *>(s->d_image);
     float4 *stack_arg = reinterpret_cast<float4 *>(s->d_stack);
@@ -1150,6 +1157,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
         HIP_TRY(hipLaunchKernel(first, dim3((unsigned)blocks), dim3((unsigned)block), d_stats ? args7 : args6, (size_t)lds_bytes, stream));
     }
     HIP_TRY(hipGetLastError());
+    s->ev_next = next_slot;               /* (only now: a launch that did not happen has zeroed nothing) */
     HIP_TRY(hipEventRecord(s->ev[slot].stop, stream));
     s->ev[slot].pending = true;
     return RT_OK;

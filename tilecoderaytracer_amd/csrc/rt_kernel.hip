@@ -1466,7 +1466,8 @@ template <bool kStats, int kMode>
 __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays,
                                             const uint32_t *__restrict__ ctl_words, float *__restrict__ out,
                                             float4 *__restrict__ bounce_stack, unsigned long long *__restrict__ stats_out,
-                                            Stats<kStats> &st, const int wave_in, const int my_xcc, const int steal) {
+                                            Stats<kStats> &st, const int wave_in, const int my_xcc, const int steal,
+                                            int &next_pop, unsigned int *const ask_head) {
     const int wave = __builtin_amdgcn_readfirstlane(wave_in);      /* the tile number is the same in all lanes: a scalar register's worth */
     const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
     const int lane = (int)(threadIdx.x & 63u);
@@ -1684,6 +1685,9 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
     }
 
     if (p.tile_prio != 0) __builtin_amdgcn_s_setprio(0);
+    /* The kernels that ask for the next tile late (scenes with clustered runs: render_body) ask HERE, when the rays are through:
+     * the answer is back by the time the unwind is done and is taken into a scalar before the pixels are stored (below). */
+    if (ask_head != nullptr && lane == 0) next_pop = (int)atomicAdd(ask_head, 1u);
     /* unwind: final_k = local_k + (rf_k * C_{k+1}) * oc_k, inside-out (:601) */
     for (int k = levels - 1; k >= 0; --k) {
         if (k < top) {
@@ -1701,6 +1705,11 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
         }
     }
 
+    /* The next tile's queue entry, asked for earlier, becomes a scalar BEFORE this tile's pixels are stored.  Waiting for a
+     * vector-memory result means waiting for every vector-memory operation issued before it -- one counter, in order, and the
+     * stores count too: a wavefront that reads the entry after its stores waits until the pixels have reached the L2, 3.5 us
+     * between two 13 us tiles of the built-in scene (timeline of round 3: "gap between consecutive tiles of a slot"). */
+    next_pop = __builtin_amdgcn_readfirstlane(next_pop);
     if (inside) {
         const int tzl_b = here(p.tile_z_log2);
         const int sx = here(tile_col) * (64 >> tzl_b) + (lane >> tzl_b);   /* x - x0 */
@@ -1737,13 +1746,24 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
 #ifndef RT_SCAN_INLINE
 #define RT_SCAN_INLINE __forceinline__
 #endif
+/* FIRST TILES WITHOUT THE QUEUES.  Every wavefront of the grid gets its first tile by arithmetic: wavefront w of workgroup b
+ * takes entry (b / 8) * (wavefronts per workgroup) + w of queue b mod 8, and a queue's head counts the entries handed out
+ * BEYOND those (entry = first_entries(queue) + head).  A launch used to begin with all of its wavefronts -- 7 168 in the plain
+ * kernels -- asking the eight heads at once: 900 atomics per word at 88 per microsecond, 10-12 us until the median wavefront
+ * had a tile (a built-in strip chunk is 100 us of work).  Every workgroup of the grid runs, so every one of these entries is
+ * rendered exactly once whatever XCD the workgroup landed on (the queue is b mod 8, not the XCC_ID: placement is speed only). */
+__device__ __forceinline__ int first_entries(const int queue) {
+    const int blocks = (int)gridDim.x;
+    return queue < blocks ? ((blocks - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * (int)(blockDim.x >> 6) : 0;
+}
+
 __device__ RT_SCAN_INLINE unsigned int queues_with_tiles(const unsigned int *tile_counter, const int n_macros) {
     const int lane = (int)(threadIdx.x & 63u);
     int left = 0;
     if (lane < RT_TILE_QUEUES) {
         const int len_k = lane < n_macros ? ((n_macros - lane + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
         const unsigned int taken = __hip_atomic_load(tile_counter + lane * RT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        left = len_k - (int)min(taken, 0x7fffffffu);
+        left = len_k - first_entries(lane) - (int)min(taken, 0x3fffffffu);
     }
     return (unsigned int)__builtin_amdgcn_ballot_w64(left > 0) & 0xFFu;
 }
@@ -1767,6 +1787,14 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * holds a scene of any size the ABI admits -- no capacity limit, and LDS (hence occupancy)
      * is spent on the bounce stack only. */
     const float4 *lds = kGlobalTables ? image : wlds;
+    /* The queue heads of the NEXT launch of this scene (RtParams::next_counters: another block of counters) are zeroed here,
+     * by nine threads of workgroup 0: launches of one scene are stream-ordered (rt_capi.hip, launch()), so nobody uses that
+     * block while this kernel runs, and the next launch finds it at zero -- no fill kernel and no dependency on one in front
+     * of every launch (3-4 us and a gap each, which a strip rendered in eight 100 us chunks pays eight times).  (Counting the
+     * wavefronts out and letting the last one re-zero this launch's own heads was measured first: 7 168 atomics on one word
+     * at the end of a 0.75 ms frame cost 0.1 ms.) */
+    if (blockIdx.x == 0 && threadIdx.x <= RT_TILE_QUEUES)
+        reinterpret_cast<unsigned int *>(p.next_counters)[threadIdx.x * RT_QUEUE_STRIDE] = 0u;
     /* FAST tables: the items' control words are read from the image in global memory (scalar loads) */
     const uint32_t *__restrict__ ctl_words = reinterpret_cast<const uint32_t *>(image) + (kFast ? p.fast_ctl_off : 0);
     /* HELP: the clustered-scene kernels get the workgroups' ray areas (128 quads each) */
@@ -1820,12 +1848,12 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * renders one at a time while the workgroup's other wavefronts stand at the desk and share every long shadow
      * scan from the first one on -- the HELP protocol with helpers that are there from the start.  The ordinary
      * tile queues skip the band.  (One loop hands out both kinds of tile, so that render_tile() is inlined once.) */
-    bool heavy_phase = false;
+    int heavy_phase = 0;               /* 0: ordinary tiles; 1: this workgroup's first HEAVY tile (number blockIdx.x, no atomic); 2: further ones */
     if constexpr (kHelp) {
         if (p.help_rays_quads != 0 && p.heavy_half >= 0) {
             uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
             if ((threadIdx.x >> 6) == 0u) {
-                heavy_phase = true;
+                heavy_phase = 1;
                 if (lane == 0) desk_write(desk, RT_DESK_DEDICATED, 1u);
             } else {
                 for (int spins = 0; spins < RT_HELP_SPIN_LIMIT; ++spins) {
@@ -1843,18 +1871,26 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * ahead of a long one waits for it while other wavefronts idle (a strip's timeline showed tiles STARTING a
      * millisecond after the queues had run dry); there the next tile is asked for when this one is done */
     const bool ask_ahead = !(kClusters || kStats) || p.n_clusters == 0;     /* the plain kernels: always */
-    int steal = 0, next_pop = 0;
+    /* FIRST TILES WITHOUT THE QUEUES (above first_entries()): the wavefront starts on queue b mod 8 -- its own XCD's when
+     * workgroups are dealt to the XCDs in turn, which nothing here relies on -- as if it had just been handed the entry
+     * (b / 8) * wavefronts + w; from there on the loop is the one it always was */
+    const int home = (int)((blockIdx.x - (unsigned int)my_xcc) & (RT_TILE_QUEUES - 1));     /* queue b mod 8, counted from this XCD's */
+    int steal = home;
+    int next_pop = (int)(blockIdx.x >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) - first_entries((int)(blockIdx.x & (RT_TILE_QUEUES - 1)));
     unsigned int candidates = ~0u;     /* the other queues that had tiles when this wavefront's own ran dry (~0: not looked yet) */
-    bool fresh = true;                 /* the current queue has not been asked yet */
+    bool fresh = false;                /* the current queue has not been asked yet */
     for (;;) {
         int wave;                      /* tile number, row-major */
-        if (kHelp && heavy_phase) {
+        if (kHelp && heavy_phase != 0) {
             unsigned int *const heavy_head = tile_counter + RT_TILE_QUEUES * RT_QUEUE_STRIDE;
-            int h = 0;
-            if (lane == 0) h = (int)atomicAdd(heavy_head, 1u);
-            h = __builtin_amdgcn_readfirstlane(h);
+            int h = (int)blockIdx.x;
+            if (heavy_phase == 2) {
+                if (lane == 0) h = (int)atomicAdd(heavy_head, 1u);
+                h = __builtin_amdgcn_readfirstlane(h) + (int)gridDim.x;
+            }
+            heavy_phase = 2;
             if (h >= (2 * p.heavy_half + 1) * p.tiles_x) {              /* the band is done: on to the ordinary tiles */
-                heavy_phase = false;
+                heavy_phase = 0;
                 uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
                 if (lane == 0) {
                     desk_write(desk, RT_DESK_DEDICATED, 0u);
@@ -1869,7 +1905,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             if (tile_row < 0 || tile_row >= p.tiles_z) continue;
             wave = tile_row * p.tiles_x + tile_col;
         } else {
-            if (steal >= RT_TILE_QUEUES) break;
+            /* (a full circle from the queue it started on) */
+            if (steal >= RT_TILE_QUEUES + (int)((blockIdx.x - (unsigned int)my_xcc) & (RT_TILE_QUEUES - 1))) break;
             const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
             unsigned int *const head = tile_counter + queue * RT_QUEUE_STRIDE;
             /* macro tiles queue, queue + 8, queue + 16, ... */
@@ -1878,7 +1915,8 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 if (lane == 0) next_pop = (int)atomicAdd(head, 1u);
                 fresh = false;
             }
-            const int pop = __builtin_amdgcn_readfirstlane(next_pop);
+            /* a head counts the entries handed out beyond the wavefronts' first ones */
+            const int pop = __builtin_amdgcn_readfirstlane(next_pop) + first_entries(queue);
             if (pop >= queue_len) {
                 /* This queue is through.  Which of the others still have tiles is found by ONE look at all the heads, when this
                  * wavefront's own queue runs dry: an atomic on each exhausted queue in turn cost 3-4 us per queue -- 25 us
@@ -1892,7 +1930,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 } else {
                     if (candidates == ~0u) {
                         const unsigned int nonempty = queues_with_tiles(tile_counter, n_macros);                   /* bit q: queue q */
-                        candidates = ((nonempty >> my_xcc) | (nonempty << (RT_TILE_QUEUES - my_xcc))) & 0xFEu;     /* bit k: queue my_xcc + k */
+                        candidates = ((nonempty >> my_xcc) | (nonempty << (RT_TILE_QUEUES - my_xcc))) & 0xFFu & ~(1u << (steal & 7));     /* bit k: queue my_xcc + k; not the one just found empty */
                     }
                     if (candidates == 0u) break;
                     steal = __builtin_ctz(candidates);
@@ -1929,18 +1967,20 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             reinterpret_cast<unsigned long long *>(p.timeline)[(size_t)wave * RT_TIMELINE_WORDS] = __builtin_amdgcn_s_memrealtime();
         const int tile_number = here(wave);
 #endif
-        render_tile<kStats, kFast ? 6 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal);
+        /* (the kernels that do not ask ahead ask inside, when the tile's rays are through -- not for a HEAVY tile, whose
+         * successor comes from the HEAVY tiles' own head) */
+        unsigned int *const ask_head = (ask_ahead || (kHelp && heavy_phase != 0)) ? nullptr
+                                     : tile_counter + ((my_xcc + steal) & (RT_TILE_QUEUES - 1)) * RT_QUEUE_STRIDE;
+        render_tile<kStats, kFast ? 6 : (kClusters ? (kRoomy ? 5 : 4) : 0)>(p, lds, wlds, help_rays, ctl_words, out, bounce_stack, stats_out, st, wave, my_xcc, steal,
+                                                                           next_pop, ask_head);
 #ifdef RT_TIMELINE
         if (p.timeline != 0ull && lane == 0) {                   /* ... when it was done, and by whom */
             unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.timeline) + (size_t)tile_number * RT_TIMELINE_WORDS;
             rec[1] = __builtin_amdgcn_s_memrealtime();
             rec[2] = (unsigned long long)blockIdx.x * 16ull + (threadIdx.x >> 6);
-            rec[3] = (kHelp && heavy_phase) ? 1ull : 0ull;
+            rec[3] = (kHelp && heavy_phase != 0) ? 1ull : 0ull;
         }
 #endif
-        /* (the queue's head is formed again here rather than kept across the tile) */
-        if (!(kHelp && heavy_phase) && !ask_ahead && lane == 0)
-            next_pop = (int)atomicAdd(tile_counter + ((my_xcc + steal) & (RT_TILE_QUEUES - 1)) * RT_QUEUE_STRIDE, 1u);
     }
     if constexpr (kHelp) {
         /* HELP: out of tiles -- serve the colleagues until they are, too */

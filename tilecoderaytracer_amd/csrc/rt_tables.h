@@ -96,6 +96,9 @@
  * a macro tile is RT_MACRO_ROWS vertically adjacent wavefront tiles */
 #define RT_TILE_QUEUES 8
 #define RT_QUEUE_STRIDE 32
+/* a launch's block of counters: the eight queue heads and the HEAVY tiles' head, each on its own cache line.  Every launch
+ * zeroes the block its scene's NEXT launch will use (RtParams::next_counters) */
+#define RT_COUNTER_WORDS ((RT_TILE_QUEUES + 1) * RT_QUEUE_STRIDE)
 #ifndef RT_MACRO_ROWS
 #define RT_MACRO_ROWS 4
 #endif
@@ -169,6 +172,8 @@ typedef struct RtParams {
     uint32_t primary[RT_PRIMARY_ITEMS * 4];
     /* one word of host memory the kernel can write (rt_scene's sticky device error): set when a HELP wait timed out */
     uint64_t error_word;
+    /* the block of counters (RT_COUNTER_WORDS u32) this scene's next launch will use: this launch zeroes its heads */
+    uint64_t next_counters;
     /* diagnostic (option "timeline"): 0, or device memory for RT_TIMELINE_WORDS u64 per wavefront tile, row-major:
      * {start, end (100 MHz constant clock), workgroup * 16 + wavefront, 1 if rendered as a HEAVY tile} */
     uint64_t timeline;
