@@ -81,8 +81,13 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
 
 /* Tuning knobs (speed only, never results).  key:
  *   "tile_z"        wavefront tile height, 1,2,4,...,64 (width = 64 / height)
- *   "block_threads" 0 = auto, else a multiple of 64 up to 1024 (a value beyond the launch bounds of
- *                   the kernel a launch picks is refused by that launch)
+ *   "block_threads" 0 = auto (256; 512 for scenes with clustered sphere runs whose tables are so large that
+ *                   four-wavefront workgroups would leave LDS room for fewer than six wavefronts per SIMD),
+ *                   else a multiple of 64 up to 1024 (a value beyond the launch bounds of the kernel a
+ *                   launch picks -- 256, or 512 for the clustered-scene kernels and the counting builds --
+ *                   is refused by that launch)
+ *   "wide"          scenes with clustered sphere runs: which kernel (-1 automatic: the 96-register one when
+ *                   LDS admits fewer than six wavefronts per SIMD anyway; 0 the 80-register one; 1 the other)
  *   "stack"         bounce stack: 0 auto, 1 LDS, 2 HBM
  *   "pairs"         scenes with clustered sphere runs: 0 = every needed leaf is tested for
  *                   the whole wavefront (round 1's route); 1 (default) = the (ray, leaf)

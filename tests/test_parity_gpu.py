@@ -153,6 +153,42 @@ def test_block_sizes_do_not_change_results(oracle, block):
     assert r.launch_info().block_threads == block
 
 
+@pytest.mark.parametrize("block", [320, 384, 512])
+def test_wide_workgroups_of_the_clustered_scene_kernel(oracle, block):
+    """The clustered-scene kernel takes workgroups of up to eight wavefronts (one LDS copy of the tables for twice as
+    many; launch() picks 512 threads by itself for scenes whose tables are large).  Frames and strips, HELP from two
+    leaves on and the HEAVY band on, so that up to seven wavefronts stand at one desk."""
+    want = oracle.OracleScene.named("grid16").render(96, 160, 8)
+    r = Renderer(HostScene.named("grid16"))
+    r.set_option("block_threads", block)
+    assert_same(r.render(96, 160, 8), want, f"grid16 block {block}")
+    assert r.launch_info().block_threads == block and r.launch_info().kernel.startswith(b"rt_render_kernel_clusters")
+    r.set_option("help", 2)
+    r.set_option("heavy", 3)
+    for _ in range(2):
+        assert_same(r.render(96, 160, 8), want, f"grid16 block {block}, help and heavy")
+    assert_same(r.render(96, 160, 8, 20, 77), want[20:77], f"grid16 block {block}, help and heavy, strip")
+
+
+def test_large_tables_get_workgroups_of_eight_wavefronts(oracle):
+    """The 1 024-sphere grid: 28 KB of tables.  Four-wavefront workgroups fit five times per CU (five wavefronts per SIMD, the
+    96-register kernel); launch() takes eight-wavefront workgroups instead, three per CU = six wavefronts per SIMD in the
+    80-register kernel, with bounce-stack levels in LDS.  Same pixels; an explicit block_threads still wins."""
+    want = oracle.OracleScene.named("grid32").render(160, 96, 4)
+    r = Renderer(HostScene.named("grid32"))
+    assert_same(r.render(160, 96, 4), want, "grid32, automatic workgroup")
+    li = r.launch_info()
+    assert li.block_threads == 512 and li.kernel == b"rt_render_kernel_clusters" and li.lds_bytes * 3 <= 160 * 1024
+    assert li.lds_bytes > li.scene_lds_bytes                      # stack levels in LDS
+    assert_same(r.render(160, 96, 4, 16, 48), want[16:48], "grid32, automatic workgroup, strip (HELP, HEAVY)")
+    r.set_option("block_threads", 256)
+    assert_same(r.render(160, 96, 4), want, "grid32, 256 threads")
+    assert r.launch_info().block_threads == 256 and r.launch_info().kernel == b"rt_render_kernel_clusters_wide"
+    r16 = Renderer(HostScene.named("grid16"))                      # small tables: four-wavefront workgroups, as before
+    r16.render(64, 64, 2)
+    assert r16.launch_info().block_threads == 256 and r16.launch_info().kernel == b"rt_render_kernel_clusters"
+
+
 @pytest.mark.parametrize("seed", range(1, 13))
 def test_random_scenes(oracle, seed):
     """Mixed primitives in shuffled index order, textured finite planes, random
@@ -1072,17 +1108,23 @@ def test_counting_build_keeps_tables_in_lds_whenever_they_fit(oracle):
 
 
 def test_launch_refuses_a_workgroup_beyond_the_kernels_launch_bounds(oracle):
-    """block_threads up to 512 is accepted as an option (the counting kernels take it), but a launch
-    whose kernel was compiled for 256 threads refuses it instead of faulting (round-2 experiment 18)."""
+    """block_threads up to 1024 is accepted as an option, but a launch whose kernel was compiled for fewer threads
+    (256: the plain kernels; 512: the clustered-scene kernels and the counting builds) refuses it instead of faulting
+    (round-2 experiment 18)."""
     from tilecoderaytracer_amd import RtError, capi
-    for name in ("builtin", "grid16"):
+    for name, too_many in (("builtin", 512), ("builtin", 320), ("grid16", 576), ("grid16", 1024), ("twomirrors", 512)):
         r = Renderer(HostScene.named(name))
-        r.set_option("block_threads", 512)
+        r.set_option("block_threads", too_many)
         with pytest.raises(RtError) as e:
             r.render(64, 64, 2)
         assert e.value.code == capi.RT_ERR_INVALID and "launch bounds" in e.value.message
         r.set_option("block_threads", 256)
         assert_same(r.render(64, 64, 2), oracle.OracleScene.named(name).render(64, 64, 2), f"{name} after the refusal")
+    r = Renderer(HostScene.named("grid32"))
+    with pytest.raises(RtError):
+        r.set_option("block_threads", 1088)
+    with pytest.raises(RtError):
+        r.set_option("block_threads", 100)
 
 
 def test_fast_tables_against_item_tables(oracle):

@@ -839,7 +839,8 @@ int primary_quads(const rt_scene *s) {
     return (s->primary_opt && s->base.n_fast_items > 0 && s->base.n_fast_items <= RT_PRIMARY_ITEMS) ? s->base.n_fast_items : 0;
 }
 
-int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, int *lds_bytes, int *stack_lds_levels, bool *global_tables) {
+int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, int *lds_bytes, int *stack_lds_levels, bool *global_tables,
+                 int block_override = 0) {
     /* Tables in LDS (staged once per workgroup), or -- large scenes -- left in global memory and read
      * through the L2 (rt_render_kernel_large): automatic beyond RT_LDS_TABLE_BYTES, where LDS would hold
      * fewer than two workgroups per CU; beyond 160 KiB it is the only way.  Option "tables". */
@@ -851,7 +852,7 @@ int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, in
     if (!*global_tables && scene_bytes > RT_MAX_LDS_BYTES)
         return fail(RT_ERR_CAPACITY, "option tables=1: the scene tables do not fit in LDS (160 KiB)");
     if (*global_tables) scene_bytes = 0;
-    *block = s->block_threads_opt ? s->block_threads_opt : 256;
+    *block = block_override ? block_override : (s->block_threads_opt ? s->block_threads_opt : 256);
     const double per_level = (double)RT_STACK_ENTRY_BYTES * (double)*block;
     const double levels = (double)max_depth + 1.0;
     double in_lds = 0.0;
@@ -897,6 +898,21 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     bool global_tables = false;
     int rc = choose_block(s, max_depth, d_stats != nullptr, &block, &lds_bytes, &stack_lds_levels, &global_tables);
     if (rc) return rc;
+    /* Scenes with clustered runs whose tables are large (the 1 024-sphere grid: 28 KB): five workgroups of four wavefronts are
+     * all that LDS admits per CU, five wavefronts per SIMD.  Workgroups of EIGHT wavefronts share one copy of the tables among
+     * twice as many: three of them fit with room for bounce-stack levels, six wavefronts per SIMD in the 80-register kernel
+     * (grid-32 frame 4.49 -> 4.36 ms, longest of 8 strips 0.98 -> 0.93 ms on one box, profiles/r04_experiments.txt 1).  Only
+     * where it raises the occupancy: with small tables the larger workgroup gains one LDS stack level and loses in strips
+     * (seven of eight wavefronts stand at the desk of a HEAVY tile). */
+    if (!d_stats && !global_tables && s->block_threads_opt == 0 && s->n_clusters > 0 && s->pairs_opt && s->wide_opt < 0 &&
+        (RT_MAX_LDS_BYTES / (size_t)lds_bytes) * 4 < 24) {
+        int block2 = 0, lds2 = 0, levels2 = 0;
+        bool global2 = false;
+        if (choose_block(s, max_depth, false, &block2, &lds2, &levels2, &global2, 512) == RT_OK && !global2 &&
+            (RT_MAX_LDS_BYTES / (size_t)lds2) * 8 >= 24) {
+            block = block2; lds_bytes = lds2; stack_lds_levels = levels2;
+        }
+    }
     if (global_tables && d_stats)
         return fail(RT_ERR_CAPACITY, s->tables_opt == 2
                         ? "the counting build keeps the tables in LDS: set option tables to 0 or 1 for it"

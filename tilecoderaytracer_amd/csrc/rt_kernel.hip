@@ -2056,7 +2056,11 @@ rt_render_kernel_large(RT_KERNEL_ARGS) {
 #ifndef RT_WAVES_PER_SIMD_CLUSTERS
 #define RT_WAVES_PER_SIMD_CLUSTERS 6
 #endif
-extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, RT_WAVES_PER_SIMD_CLUSTERS)
+/* (workgroups of up to eight wavefronts: scenes whose tables are large share one LDS copy among more of them, launch() in rt_capi.hip) */
+#ifndef RT_BLOCK_BOUND_CLUSTERS
+#define RT_BLOCK_BOUND_CLUSTERS 512
+#endif
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND_CLUSTERS, RT_WAVES_PER_SIMD_CLUSTERS)
 rt_render_kernel_clusters(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
@@ -2067,7 +2071,7 @@ rt_render_kernel_clusters(RT_KERNEL_ARGS) {
 #ifndef RT_WAVES_PER_SIMD_WIDE
 #define RT_WAVES_PER_SIMD_WIDE 5
 #endif
-extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND, RT_WAVES_PER_SIMD_WIDE)
+extern "C" __global__ void __launch_bounds__(RT_BLOCK_BOUND_CLUSTERS, RT_WAVES_PER_SIMD_WIDE)
 rt_render_kernel_clusters_wide(RT_KERNEL_ARGS) {
     RT_PARAMS_FROM_KERNARG(p, p_in_kernarg);
     render_body<false, false, true, true>(p, image, out, tile_counter, bounce_stack, nullptr, help_area);
