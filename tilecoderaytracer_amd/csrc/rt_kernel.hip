@@ -449,6 +449,12 @@ __device__ __forceinline__ int here(int uniform_value) {
     return __builtin_amdgcn_readfirstlane(uniform_value);   /* ... and scalar again */
 }
 
+/* a value the compiler may not compute with before this point (an empty volatile asm is never hoisted or speculated) */
+__device__ __forceinline__ V3 not_speculated(V3 v) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z));
+    return v;
+}
+
 __device__ __forceinline__ float uniform_f(const float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
@@ -1626,7 +1632,11 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                     const float4 m1 = lds[p.mat_off + mat * RT_MAT_QUADS + 1];
                     const V3 object_color = entry_colour(p, lds, m0, __float_as_uint(m1.w), texsel);
                     const float diffuse_factor = m0.w, specular_factor = m1.x;
-                    const V3 normal_dir = normals_are_unit ? N : renormalize3(N);   /* CollisionObject ctor: Ray(point, normal) re-normalises, src/SceneObject.h:62 */
+                    /* CollisionObject ctor: Ray(point, normal) re-normalises, src/SceneObject.h:62.  (The rare path goes through an
+                     * opaque copy: left to itself the compiler computes the square root and the three divides before the light
+                     * loop, on every bounce level of every tile, speculatively -- 55 instructions and two spilled registers.) */
+                    V3 normal_dir = N;
+                    if (!normals_are_unit) normal_dir = renormalize3(not_speculated(N));
                     const V3 light_color = xyz(l1);
                     /* cosineShade, :654-701 */
                     if (diffuse_factor > (float)0) {
@@ -1642,7 +1652,8 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                         C.z = (C.z > 1.0f) ? 1.0f : C.z;
                     }
                     /* specular, :561-588 */
-                    const V3 Nn = normals_are_unit ? normal_dir : renormalize3(normal_dir);  /* third normalisation, :566-567 */
+                    V3 Nn = normal_dir;                                                       /* third normalisation, :566-567 */
+                    if (!normals_are_unit) Nn = renormalize3(not_speculated(normal_dir));
                     const V3 R = sub3(light_ray, scale3(Nn, 2.0f * dot3(light_ray, Nn)));
                     const float dot = dot3(d, R);
                     if (dot > (float)0) {
