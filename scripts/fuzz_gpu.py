@@ -1,13 +1,15 @@
 """Randomised parity sweep, GPU kernel vs CPU oracle (development aid; the permanent cases live in tests/).
 
-usage: fuzz_gpu.py [first_seed=1000] [count=200] [only=0..3] [option=value ...]"""
+usage: fuzz_gpu.py [first_seed=1000] [count=200] [only=0..3] [far=1] [option=value ...]
+far=1: every scene is a far-origin grazing scene (scene_gen.build_far_grazing) in a strip 8 columns wide and 4 096 ... 32 768 rows
+tall, whose rows around the middle hit the ground 1e4 ... 6e4 units away"""
 import os, sys, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
 import oracle_lib                                   # noqa: E402
-from scene_gen import build_random, build_room, build_sphere_field   # noqa: E402
+from scene_gen import build_far_grazing, build_random, build_room, build_sphere_field   # noqa: E402
 from tilecoderaytracer_amd import HostScene, Renderer    # noqa: E402
 
 kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
@@ -17,7 +19,10 @@ for seed in range(first, first + count):
     if "only" in kv and seed % 4 != int(kv["only"]):    # only=0: the clustered sphere fields, only=1: the rooms
         continue
     rng = np.random.RandomState(seed)
-    if seed % 4 == 1:                   # axis-aligned rooms: rectangles, slabs, lights hugging surfaces, scales (round 3's culls)
+    if kv.get("far") == "1":
+        mk = lambda s: build_far_grazing(s, seed)
+        W, H, depth = 8, int(rng.choice([4096, 16384, 32768])), int(rng.randint(1, 5))
+    elif seed % 4 == 1:                   # axis-aligned rooms: rectangles, slabs, lights hugging surfaces, scales (round 3's culls)
         mk = lambda s: build_room(s, seed)
         W, H, depth = int(rng.randint(8, 120)), int(rng.randint(8, 120)), int(rng.randint(0, 7))
     elif seed % 4 == 0:
@@ -35,7 +40,7 @@ for seed in range(first, first + count):
     orc = mk(oracle_lib.OracleScene())
     r = Renderer(host)
     for k, v in kv.items():                             # any other key=value: an rt_set_option for every scene (help=2 heavy=1 ...)
-        if k not in ("first_seed", "count", "only", "learn"):
+        if k not in ("first_seed", "count", "only", "learn", "far"):
             r.set_option(k, int(v))
     if seed % 3 == 0:
         r.set_option("tile_z", int(2 ** rng.randint(0, 7)))

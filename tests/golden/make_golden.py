@@ -22,9 +22,11 @@ for key in ("b64d4", "g32_64d4", "g16_64d8"):
     img.tofile(os.path.join(HERE, key + ".f32"))
     print("wrote", key, digest)
 
-extra = {}
+extra = {"_about": "SHA-256 of oracle renders (oracle/rt_oracle.c). ORACLE-ONLY pins: SURVEY.md Appendix D's digests cover the built-in "
+                   "scene and the NO-shadow grids; the shadowed grid32 / grid16 scenes (the ones bench.py and the 4096^2 tests render) and "
+                   "twomirrors have no digest from the reference, so these values pin the GPU path to the oracle, not the oracle to the reference."}
 for name, W, H, depth in (("grid32", 64, 64, 4), ("grid16", 64, 64, 8), ("twomirrors", 48, 48, 6),
-                          ("builtin", 500, 504, 50)):
+                          ("builtin", 500, 504, 50), ("grid32", 256, 256, 4), ("grid16", 256, 256, 8)):
     img = oracle_lib.OracleScene.named(name).render(W, H, depth)
     extra[f"{name}_{W}x{H}_d{depth}"] = oracle_lib.sha256(img)
 json.dump(extra, open(os.path.join(HERE, "extra.json"), "w"), indent=1, sort_keys=True)

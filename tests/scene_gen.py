@@ -178,3 +178,57 @@ def build_room(scene, seed):
         scene.set_object_indices(0, 1)
     scene.camera_two_mirrors()
     return scene
+
+
+def build_far_grazing(scene, seed):
+    """Rays that ARRIVE from far away at tilted rectangles near the origin, grazing them (round-3 advisor's case for the tight
+    plane boxes, csrc/rt_capi.hip box_item()): the hit parameter t = num / den of a ray that starts 1e4-6e4 units away loses
+    about 1e-6 of that distance to cancellation in n.o + dto, and t d_k + o_k cancels again.
+      * shadow rays: the horizontal two-mirrors camera (eye (0,-1,2.5) looking along +y) sees a ground plane to the horizon
+        -- in a strip thousands of rows tall the rows just below the middle hit it 1e4 ... 6e4 units away -- and the lights sit
+        among the rectangles, near the origin, so those shadow segments come in almost level and graze the nearly level plates;
+      * nearest-hit rays: a mirror wall y = D (D = 1e4 ... 6e4) sends the camera rays back the same way.
+    Plates: nearly horizontal (normal (a, b, 1), |a|, |b| <= 0.05), nearly vertical facing the rays, and arbitrary; some are
+    mirrors.  Same calls on HostScene and OracleScene."""
+    rng = np.random.RandomState(seed)
+    for k in range(int(rng.randint(1, 3))):
+        i = scene.add_sphere((f32(rng.uniform(-3, 3)), f32(rng.uniform(3, 9)), f32(rng.uniform(1.0, 5.0))), f32(0.15))
+        scene.set_light(i)
+        scene.set_intensity(i, f32(rng.uniform(0.5, 1.0)))
+    i = scene.add_infinite_plane((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+    scene.set_color(i, (0, 1, 0))
+    scene.set_reflective(i, f32(rng.choice([0.0, 0.5])))
+    scene.set_diffuse(i, 0.5)
+    if rng.rand() < 0.5:
+        scene.set_checkerboard(i, (1, 1, 1), (0, 0, 0), 3.0, 3.0)
+    far = f32(rng.choice([1.0e4, 3.0e4, 6.0e4]))
+    i = scene.add_infinite_plane((0.0, far, 0.0), (0.0, -1.0, 0.0), (1.0, 0.0, 0.0))
+    scene.set_color(i, (1, 1, 1))
+    scene.set_reflective(i, 1.0)
+    scene.set_diffuse(i, 0.0)
+    for k in range(int(rng.randint(4, 14))):
+        o = (f32(rng.uniform(-5, 3)), f32(rng.uniform(2, 14)), f32(rng.uniform(0.2, 4.5)))
+        style = rng.randint(3)
+        if style == 0:          # nearly level plate: level shadow rays graze it
+            n = (f32(rng.uniform(-0.05, 0.05)), f32(rng.uniform(-0.05, 0.05)), f32(rng.choice([-1.0, 1.0])))
+            h = (1.0, f32(rng.uniform(-0.3, 0.3)), 0.0)
+        elif style == 1:        # nearly vertical, along the rays' way: grazed by rays along +-y
+            n = (f32(rng.choice([-1.0, 1.0])), f32(rng.uniform(-0.03, 0.03)), f32(rng.uniform(-0.03, 0.03)))
+            h = (0.0, 1.0, f32(rng.uniform(-0.2, 0.2)))
+        else:
+            n = tuple(f32(v) for v in rng.uniform(-1, 1, 3))
+            h = tuple(f32(v) for v in rng.uniform(-1, 1, 3))
+        i = scene.add_finite_plane_axes(o, n, h, f32(rng.uniform(1, 8)), f32(rng.uniform(1, 8)))
+        scene.set_color(i, PALETTE[rng.randint(len(PALETTE))])
+        r = rng.rand()
+        if r < 0.3:
+            scene.set_reflective(i, f32(rng.choice([0.5, 1.0])))
+            scene.set_diffuse(i, f32(rng.choice([0.0, 0.5])))
+        elif r < 0.6:
+            scene.set_specular(i, f32(rng.uniform(0, 1)))
+    for k in range(int(rng.randint(0, 4))):
+        i = scene.add_sphere((f32(rng.uniform(-4, 4)), f32(rng.uniform(3, 12)), f32(rng.uniform(0.5, 3))), f32(rng.uniform(0.3, 1.2)))
+        scene.set_color(i, PALETTE[rng.randint(len(PALETTE))])
+    scene.set_object_indices(0, 1)
+    scene.camera_two_mirrors()
+    return scene

@@ -395,13 +395,19 @@ int pack_scene(rt_scene *s) {
         const float INF = INFINITY;
         /* Padding.  A sphere's box also has to hold what the reference's coarse float sphere test reports
          * (box_needed() in rt_kernel.hip): 1 % of its extent here plus the kernel's distance-proportional
-         * RT_SPHERE_SLACK.  A plane's hit point p = t d + o is exact up to the rounding of the sum, a few ulp
-         * of the coordinates involved: 1e-4 of the box's magnitude (500 ulp) covers the part that scales with
-         * where the rectangle is, the kernel's RT_PLANE_SLACK the part that scales with the distance travelled;
-         * such items carry RT_ITEM_TIGHT.  (With the sphere padding a 14-unit wall was 0.28 thick and, e.g., a
-         * light 0.01 in front of it made it a candidate of every shadow scan towards that light; at 2e-5 of the
-         * magnitude (170 ulp) a plane is not even a candidate of the shadow rays that START on it, 1e-3 in front
-         * of it -- src/SceneFinitePlane.h:11 --, in scenes up to a few tens of units across.) */
+         * RT_SPHERE_SLACK.  A plane item (RT_ITEM_TIGHT) gets 2e-5 + 2e-5 of the box's magnitude: 170 ulp of the
+         * largest coordinate.  What it has to cover is the part of the hit point's error that scales with WHERE the
+         * rectangle is: p = t d + o is rounded twice per component (2 ulp of |p_k|) and the bounds test
+         * (p - plane_origin).h, 0 <= x <= h_dist adds a few ulp of the rectangle's coordinates -- well under 20 ulp
+         * in all.  The part that scales with the distance TRAVELLED -- t d_k and o_k cancel when a ray comes from
+         * far away, and t itself carries the relative error of n.o + dto: about 1e-6 of the distance for origins
+         * 1e4-6e4 away, grazing or not -- is the kernel's per-axis RT_PLANE_SLACK, 1e-5 of the distance on that
+         * axis (an axis on which the ray hardly moves has a hit-point error that small, too: the error of t is
+         * multiplied by d_k).  tests/scene_gen.py's far-origin grazing scenes and scripts/fuzz_gpu.py's `far` mode
+         * exercise exactly that against the oracle.  (With the sphere padding a 14-unit wall was 0.28 thick and,
+         * e.g., a light 0.01 in front of it made it a candidate of every shadow scan towards that light; at 170 ulp
+         * a plane is not even a candidate of the shadow rays that START on it, 1e-3 in front of it --
+         * src/SceneFinitePlane.h:11 --, in scenes up to a few tens of units across.) */
         auto box_item = [&](std::vector<Quad> &out, const double lo[3], const double hi[3], uint32_t bits,
                             uint32_t word1, bool unbounded) {
             double ext = 0.0, mag = 0.0;
@@ -1358,9 +1364,16 @@ int rt_learn_tile_order(rt_scene *s, const rt_camera_desc *cam, int W, int H, in
      * from the longest tile's row upwards or downwards.  (Trying the HEAVY band and the tile priorities the other way round per
      * shape as well gave nothing beyond the strip model's +-4 %: profiles/r03_experiments.txt 23-24) */
     HIP_TRY(hipSetDevice(s->device));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    {
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            s->row_peak.clear(); s->row_sum.clear();
+            return fail(RT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+        }
+    }
     rc = RT_OK;
     auto frame_ms = [&]() {
         float shortest = 1e30f;
@@ -1387,7 +1400,7 @@ int rt_learn_tile_order(rt_scene *s, const rt_camera_desc *cam, int W, int H, in
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (rc != RT_OK) s->learned_sweep = -1;
+    if (rc != RT_OK) { s->learned_sweep = -1; s->row_peak.clear(); s->row_sum.clear(); }
     return rc;
 }
 
@@ -1483,6 +1496,7 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
     if (!std::strcmp(key, "learned_order")) {
         if (value != 0) return fail(RT_ERR_INVALID, "learned_order accepts 0 only (forget the order of rt_learn_tile_order)");
         s->row_peak.clear(); s->row_sum.clear();
+        s->learned_sweep = -1;
         return RT_OK;
     }
     if (!std::strcmp(key, "tile_prio")) {
