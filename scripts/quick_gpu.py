@@ -16,7 +16,7 @@ for name, S, d in cases:
     st = torch.cuda.current_stream().cuda_stream
     r.render_device(S, S, d, 0, S, buf.data_ptr(), st); torch.cuda.synchronize()
     r.reset_timing()
-    n = 5 if name == "builtin" else 2
+    n = 20 if name == "builtin" else 3
     for _ in range(n):
         r.render_device(S, S, d, 0, S, buf.data_ptr(), st)
     torch.cuda.synchronize()

@@ -860,7 +860,8 @@ int choose_block(const rt_scene *s, int max_depth, bool counting, int *block, in
     if (*global_tables) scene_bytes = 0;
     *block = block_override ? block_override : (s->block_threads_opt ? s->block_threads_opt : 256);
     const double per_level = (double)RT_STACK_ENTRY_BYTES * (double)*block;
-    const double levels = (double)max_depth + 1.0;
+    /* levels 0 .. max_depth - 1 can push an entry (the last level's reflection is folded where it is found: rt_kernel.hip) */
+    const double levels = (double)max_depth;
     double in_lds = 0.0;
     if (s->stack_opt == 1) {
         in_lds = levels;
@@ -910,13 +911,21 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
      * (grid-32 frame 4.49 -> 4.36 ms, longest of 8 strips 0.98 -> 0.93 ms on one box, profiles/r04_experiments.txt 1).  Only
      * where it raises the occupancy: with small tables the larger workgroup gains one LDS stack level and loses in strips
      * (seven of eight wavefronts stand at the desk of a HEAVY tile). */
-    if (!d_stats && !global_tables && s->block_threads_opt == 0 && s->n_clusters > 0 && s->pairs_opt && s->wide_opt < 0 &&
-        (RT_MAX_LDS_BYTES / (size_t)lds_bytes) * 4 < 24) {
-        int block2 = 0, lds2 = 0, levels2 = 0;
-        bool global2 = false;
-        if (choose_block(s, max_depth, false, &block2, &lds2, &levels2, &global2, 512) == RT_OK && !global2 &&
-            (RT_MAX_LDS_BYTES / (size_t)lds2) * 8 >= 24) {
-            block = block2; lds_bytes = lds2; stack_lds_levels = levels2;
+    /* Small tables and a deep recursion (the 256-sphere grid at depth 8), WHOLE frames: eight-wavefront workgroups at the same six
+     * wavefronts per SIMD keep one bounce-stack level more in LDS (one copy of the tables less per CU), and every level that
+     * stays out of HBM takes a row per workgroup out of a working set that is as large as the XCD's L2 (HBM traffic of that
+     * frame 7.0 -> 5.x times the algorithmic bytes at the same frame time; strips keep four wavefronts per workgroup: seven
+     * helpers at the desk of a HEAVY tile lose more than the level gains).  profiles/r04_experiments.txt 4 */
+    if (!d_stats && !global_tables && s->block_threads_opt == 0 && s->n_clusters > 0 && s->pairs_opt && s->wide_opt < 0) {
+        const bool few_waves = (RT_MAX_LDS_BYTES / (size_t)lds_bytes) * 4 < 24;
+        const bool whole_frame = (long long)(x1 - x0) * 4 > (long long)W * 3;
+        if (few_waves || (whole_frame && stack_lds_levels < max_depth)) {
+            int block2 = 0, lds2 = 0, levels2 = 0;
+            bool global2 = false;
+            if (choose_block(s, max_depth, false, &block2, &lds2, &levels2, &global2, 512) == RT_OK && !global2 &&
+                (RT_MAX_LDS_BYTES / (size_t)lds2) * 8 >= 24 && (few_waves || levels2 > stack_lds_levels)) {
+                block = block2; lds_bytes = lds2; stack_lds_levels = levels2;
+            }
         }
     }
     if (global_tables && d_stats)
@@ -1134,7 +1143,7 @@ int launch(rt_scene *s, const rt_camera_desc *cam, int W, int H, int x0, int x1,
     HIP_TRY(hipFuncSetAttribute(first, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     /* bounce stack: one slice per workgroup of the persistent grid */
     {
-        const double need_d = stack_lds_levels > max_depth ? 16.0
+        const double need_d = stack_lds_levels >= max_depth ? 16.0
                                            : (double)blocks * (double)block * (double)(max_depth + 1) * RT_STACK_ENTRY_BYTES;
         if (need_d > 8.0e9)
             return fail(RT_ERR_CAPACITY, "max_depth too large: the bounce stack would exceed 8 GB of HBM");

@@ -1674,7 +1674,20 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
             const int mat = (int)(lds_u32[p.objinfo_off * 4 + idx] >> 20);
             const float reflective_factor = lds[p.mat_off + mat * RT_MAT_QUADS + 1].y;
             const float n_dot_incoming = dot3(N, d);         /* src/SceneObject.h:65 */
-            if (reflective_factor > (float)0) {
+            if (reflective_factor > (float)0 && level == p.max_depth) {
+                /* The reflected ray of the LAST level is never traced: the call at max_depth + 1 returns NULL_COLOR at once
+                 * (:454-455), so this level's sum can be formed here, with the operations the unwind below would apply to its
+                 * stack entry -- final = local + (rf * NULL_COLOR) * colour, :601 -- and the entry (for depth 4, the one level
+                 * that does not fit LDS: 26 MB of HBM writes per built-in frame) need not exist, nor the reflected direction. */
+                const uint32_t info = lds_u32[p.objinfo_off * 4 + idx];
+                const int mat_last = (int)(info >> 20);
+                const float4 m0 = lds[p.mat_off + mat_last * RT_MAT_QUADS];
+                const float4 m1 = lds[p.mat_off + mat_last * RT_MAT_QUADS + 1];
+                const V3 oc = entry_colour(p, lds, m0, __float_as_uint(m1.w), texsel);
+                const V3 refl = mk(null_color.x * m1.y * oc.x, null_color.y * m1.y * oc.y, null_color.z * m1.y * oc.z);
+                C = add3(C, refl);
+                alive = false;
+            } else if (reflective_factor > (float)0) {
                 const V3 reflected = mk(-2 * N.x * n_dot_incoming + d.x,
                                         -2 * N.y * n_dot_incoming + d.y,
                                         -2 * N.z * n_dot_incoming + d.z);
