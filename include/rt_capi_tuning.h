@@ -107,6 +107,14 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   nearest-first early exit, no sphere clustering, no
  *                   axis-aligned route (the slow baseline the fast path is
  *                   checked against, pixel for pixel, in tests/)
+ *   "svox"          scenes with clustered sphere runs, at most 64 shadow items and two lights: SHADOW
+ *                   VOXELS -- the host lays a grid over the region the leaves occupy (plus a few
+ *                   ever larger cells beyond it on every side) and notes, per voxel and light, which
+ *                   leaves can block the segment from ANY point of the voxel to that light (every
+ *                   slack of the float sphere test included); a shadow scan ORs its lanes' voxel
+ *                   masks and drops every other candidate leaf before the per-ray box tests.
+ *                   -1 (default) = automatic: 4 096 voxels, scenes with at least 24 leaves;
+ *                   0 = no table; n = at most n voxels, from 4 leaves on
  *   "help"          scenes with clustered sphere runs: 1 = a wavefront that has run out
  *                   of tiles stays and tests candidate leaves of its workgroup's long
  *                   shadow scans (a desk in LDS, a shared cursor over the candidates;

@@ -618,6 +618,36 @@ def test_random_sphere_fields(oracle, seed, n):
     assert_same(img, want, f"field {seed} tall strip")
 
 
+@pytest.mark.parametrize("svox", [0, 800, 4096, 300000])
+@pytest.mark.parametrize("name,W,H,depth", [("grid16", 96, 160, 8), ("grid32", 128, 96, 4), ("grid9", 50, 120, 3)])
+def test_shadow_voxels_on_the_sphere_grids(oracle, name, W, H, depth, svox):
+    """rt_set_option("svox", n): the per-voxel, per-light masks of leaves that can block (SHADOW VOXELS, csrc/rt_tables.h) with
+    no table, the coarsest grid there is (a core of one or two cells per axis: nearly everything lies in the tail cells), the
+    automatic budget and a very fine grid -- forced on from four leaves (automatic: from 24)."""
+    r = Renderer(HostScene.named(name))
+    r.set_option("svox", svox)
+    assert_same(r.render(W, H, depth), oracle.OracleScene.named(name).render(W, H, depth), f"{name} svox={svox}")
+
+
+@pytest.mark.parametrize("seed,n", [(1, 64), (3, 200), (4, 333), (11, 700), (12, 1000)])
+def test_shadow_voxels_on_random_sphere_fields(oracle, seed, n):
+    """The same on clustered fields of spheres of mixed sizes with the lights INSIDE the field's box, seen to the horizon: shading
+    points from inside the leaves' boxes to tens of thousands of units away (the tail cells, and beyond the last one), every
+    slack of the float sphere test at work.  Whole small frames and the rows around the horizon of a
+    4 096-row strip, table forced on / automatic / off."""
+    from scene_gen import build_sphere_field
+    host = build_sphere_field(HostScene.empty(), seed, n_spheres=n)
+    orc = build_sphere_field(oracle.OracleScene(), seed, n_spheres=n)
+    want_small = orc.render(96, 80, 4)
+    W, H = 16, 4096
+    want_tall = orc.render(W, H, 3, 0, W)
+    r = Renderer(host)
+    for svox in (1500, -1, 0):
+        r.set_option("svox", svox)
+        assert_same(r.render(96, 80, 4), want_small, f"field {seed} svox={svox}")
+        assert_same(r.render(W, H, 3), want_tall, f"field {seed} tall strip svox={svox}")
+
+
 def test_counting_build_matches_and_counts(oracle):
     r = Renderer(HostScene.builtin())
     img, st = r.render_stats(64, 64, 3)

@@ -100,6 +100,7 @@ struct rt_scene {
     int tight_planes = 1;         /* plane items: boxes padded for a plane's rounding only (RT_ITEM_TIGHT); 0: the sphere padding */
     int cluster_leaf = -1;        /* spheres per cluster leaf for long sphere runs; 0 = no clustering, -1 = by the run's length (auto_leaf()) */
     int cull_opt = 1;             /* 0: plain in-order scans -- no bundle cull, no nearest-first exit, no clustering, no AA route */
+    int svox_opt = -1;            /* SHADOW VOXELS (scenes with clustered runs): -1 = automatic (RT_SVOX_MAX_CELLS voxels), 0 = none, n = at most n voxels */
     int n_clusters = 0;
     /* tile queue heads, one per in-flight launch (same ring as the events) */
     unsigned int *d_counters = nullptr;
@@ -214,6 +215,165 @@ int aa_class(const rt_object_desc &o, float *sn, float *sh, float *sv, int *a_ax
 bool all_finite(const rt_object_desc &o) {
     return std::isfinite(o.origin[0]) && std::isfinite(o.origin[1]) && std::isfinite(o.origin[2]) &&
            std::isfinite(o.radius);
+}
+
+/* SHADOW VOXELS (rt_tables.h, RtParams::svox_*).  The shadow scans of a wavefront cull the scene's items against ONE box around
+ * its 64 shading points; after a bounce those lie all over the scene and the box is large: 9 candidate leaves per scan on the
+ * 1 024-sphere grid where 2.3 are needed by any ray, each of them a box test for the whole wavefront.  What a single shading
+ * point needs depends on where it is and on the light only -- neither changes from frame to frame -- so the host answers the
+ * question once per scene for every VOXEL of a grid laid over the region the leaves occupy: which shadow items can block the
+ * segment from some point of the voxel to light l?  A scan then ORs its lanes' voxel masks and ANDs them into the candidates.
+ *
+ * Exactness.  A leaf may be left out of a voxel's mask only if no member sphere can be reported by the reference's float test
+ * (src/SceneSphere.cpp:50-116) for a shadow ray that starts in the voxel.  box_needed() (rt_kernel.hip) derives what that takes:
+ * the ray must meet the leaf's box grown by RT_SPHERE_SLACK of the L1 distance `far` from the ray's origin to the box's farthest
+ * corner, between its origin and the light (give or take 2.4e-7 far).  Here: the box is grown by that slack for the LARGEST far any
+ * point of the voxel has, plus 1e-5 far + 1e-5 for what separates the float ray from the exact segment (the direction's
+ * normalisation, the distance to the light: a few 1e-7 of the length each); the voxel is grown by 1e-4 of a cell for the rounding
+ * of the kernel's voxel index (its two float operations err by less than 1e-5 cells); and the set of segments from the voxel to
+ * the light is the hull of a box and a point: at parameter s the box of half-extent (1 - s) e around c + s (L - c), so
+ * "meets the grown box" is an intersection of intervals in s -- exact in real arithmetic, evaluated in double.  A shading point
+ * outside the grid (or a NaN) gets all ones.  Plain items (planes, single spheres) are always set: the bundle cull's business. */
+struct ShadowVoxels {
+    std::vector<uint64_t> masks;          /* [cell][RT_SVOX_MAX_LIGHTS] */
+    int n[3] = {0, 0, 0};                 /* core cells per axis (the grid has n + 2 RT_SVOX_TAIL per axis) */
+    float lo[3] = {0, 0, 0}, scale[3] = {0, 0, 0};
+};
+
+bool hull_meets_box(const double c[3], const double e[3], const double L[3], const double lo[3], const double hi[3]) {
+    double s_lo = 0.0, s_hi = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        const double m = 0.5 * (lo[k] + hi[k]), h = 0.5 * (hi[k] - lo[k]);
+        const double a = c[k] - m, g = L[k] - c[k], r = h + e[k];
+        /* |a + s g| <= r - s e:   s (g + e) <= r - a   and   s (e - g) <= r + a */
+        const double A[2] = {g + e[k], e[k] - g}, B[2] = {r - a, r + a};
+        for (int j = 0; j < 2; ++j) {
+            if (A[j] > 0.0) s_hi = std::min(s_hi, B[j] / A[j]);
+            else if (A[j] < 0.0) s_lo = std::max(s_lo, B[j] / A[j]);
+            else if (B[j] < 0.0) return false;
+        }
+        if (s_lo > s_hi + 1e-9) return false;
+    }
+    return true;
+}
+
+/* One axis of the grid, as svox_axis_cell() in rt_kernel.hip numbers it: RT_SVOX_TAIL cells below the core, growing 16-fold each
+ * (distance d beyond the core in cells: cell j holds 16^j <= 1 + 15 d < 16^(j+1)), n core cells, RT_SVOX_TAIL above.  The bounds
+ * are what the kernel's float arithmetic can put into the cell: (x - lo) * scale, the distance beyond the core and 1 + 15 d are
+ * rounded once each (relative 6e-8 each; x - lo absolutely by half an ulp of the larger operand), so every cell gets 1e-5 of 1 + 15 d,
+ * 1e-4 of a core cell and 1e-6 of the coordinates' magnitude on either side. */
+void svox_axis_bounds(float lo_f, float scale_f, int n, std::vector<double> &cell_lo, std::vector<double> &cell_hi) {
+    const double lo = lo_f, scale = scale_f;
+    const int N = n + 2 * RT_SVOX_TAIL;
+    cell_lo.assign((size_t)N, 0.0);
+    cell_hi.assign((size_t)N, 0.0);
+    auto beyond = [&](int j, double *d_lo, double *d_hi) {       /* tail cell j: the distances beyond the core, in cells */
+        *d_lo = (std::pow(16.0, j) * (1.0 - 1e-5) - 1.0) / 15.0 - 1e-4;
+        *d_hi = (std::pow(16.0, j + 1) * (1.0 + 1e-5) - 1.0) / 15.0 + 1e-4;
+    };
+    for (int idx = 0; idx < N; ++idx) {
+        double a, b;
+        if (idx < RT_SVOX_TAIL) {
+            double d_lo, d_hi;
+            beyond(RT_SVOX_TAIL - 1 - idx, &d_lo, &d_hi);
+            a = lo - d_hi / scale; b = lo - d_lo / scale;
+        } else if (idx < RT_SVOX_TAIL + n) {
+            const double i = idx - RT_SVOX_TAIL;
+            a = lo + (i - 1e-4) / scale; b = lo + (i + 1.0 + 1e-4) / scale;
+        } else {
+            double d_lo, d_hi;
+            beyond(idx - RT_SVOX_TAIL - n, &d_lo, &d_hi);
+            a = lo + ((double)n + d_lo) / scale; b = lo + ((double)n + d_hi) / scale;
+        }
+        cell_lo[(size_t)idx] = a - 1e-6 * (std::fabs(a) + std::fabs(lo));
+        cell_hi[(size_t)idx] = b + 1e-6 * (std::fabs(b) + std::fabs(lo));
+    }
+}
+
+/* items: 2 quads each ({lo.xyz, bits}, {hi.xyz, word}); the leaves are the items from first_leaf on; lights: RT_LIGHT_QUADS each */
+bool shadow_voxels(const std::vector<Quad> &items, int first_leaf, const std::vector<Quad> &lights, int max_cells, int min_leaves, ShadowVoxels *out) {
+    const int n_items = (int)(items.size() / 2), n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
+    const int n_leaves = n_items - first_leaf;
+    if (n_items > RT_SVOX_MAX_ITEMS || n_lights < 1 || n_lights > RT_SVOX_MAX_LIGHTS || n_leaves < min_leaves) return false;
+    /* the core: around the leaves, and on an axis where the other items' bounded sides reach further -- a ceiling above the
+     * field -- out to those, unless that would more than double the largest extent.  Shading points beyond it -- the ground
+     * in front of a field of spheres, out to the horizon -- fall into the tail cells. */
+    double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
+    for (int i = first_leaf; i < n_items; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double a = items[(size_t)2 * i].v[k], b = items[(size_t)2 * i + 1].v[k];
+            if (!std::isfinite(a) || !std::isfinite(b)) return false;
+            glo[k] = std::min(glo[k], a);
+            ghi[k] = std::max(ghi[k], b);
+        }
+    const double largest = std::max(ghi[0] - glo[0], std::max(ghi[1] - glo[1], ghi[2] - glo[2]));
+    if (!(largest > 0.0) || !std::isfinite(largest)) return false;
+    for (int k = 0; k < 3; ++k) {
+        double lo = glo[k], hi = ghi[k];
+        for (int i = 0; i < first_leaf; ++i) {
+            const double a = items[(size_t)2 * i].v[k], b = items[(size_t)2 * i + 1].v[k];
+            if (std::isfinite(a)) lo = std::min(lo, a);
+            if (std::isfinite(b)) hi = std::max(hi, b);
+        }
+        if (hi - lo <= 2.0 * largest) { glo[k] = lo; ghi[k] = hi; }
+        glo[k] -= 1e-3 * largest;
+        ghi[k] += 1e-3 * largest;
+    }
+    for (int l = 0; l < n_lights; ++l)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(lights[(size_t)l * RT_LIGHT_QUADS].v[k])) return false;
+    /* cubic core cells, as small as the budget allows */
+    if (max_cells < (2 * RT_SVOX_TAIL + 1) * (2 * RT_SVOX_TAIL + 1) * (2 * RT_SVOX_TAIL + 1)) return false;
+    double cell = std::cbrt((ghi[0] - glo[0]) * (ghi[1] - glo[1]) * (ghi[2] - glo[2]) / (double)max_cells);
+    int n[3], N[3];
+    for (int tries = 0;; ++tries) {
+        long long cells = 1;
+        for (int k = 0; k < 3; ++k) {
+            n[k] = (int)std::min(256.0, std::max(1.0, std::ceil((ghi[k] - glo[k]) / cell)));
+            N[k] = n[k] + 2 * RT_SVOX_TAIL;
+            cells *= N[k];
+        }
+        if (cells <= max_cells) break;
+        if (tries > 400) return false;
+        cell *= 1.03;
+    }
+    std::vector<double> clo[3], chi[3];
+    for (int k = 0; k < 3; ++k) {
+        out->n[k] = n[k];
+        out->lo[k] = (float)glo[k];
+        out->scale[k] = (float)((double)n[k] / (ghi[k] - glo[k]));
+        if (!std::isfinite(out->lo[k]) || !std::isfinite(out->scale[k]) || !(out->scale[k] > 0.0f)) return false;
+        svox_axis_bounds(out->lo[k], out->scale[k], n[k], clo[k], chi[k]);
+    }
+    const uint64_t plain = first_leaf >= 64 ? ~0ull : ((1ull << first_leaf) - 1ull);
+    /* two masks per voxel whatever the number of lights (a quad: one load) */
+    out->masks.assign((size_t)N[0] * N[1] * N[2] * RT_SVOX_MAX_LIGHTS, plain);
+    double L[RT_SVOX_MAX_LIGHTS][3];
+    for (int l = 0; l < n_lights; ++l)
+        for (int k = 0; k < 3; ++k) L[l][k] = lights[(size_t)l * RT_LIGHT_QUADS].v[k];
+    for (int z = 0; z < N[2]; ++z)
+        for (int y = 0; y < N[1]; ++y)
+            for (int x = 0; x < N[0]; ++x) {
+                const double vlo[3] = {clo[0][(size_t)x], clo[1][(size_t)y], clo[2][(size_t)z]};
+                const double vhi[3] = {chi[0][(size_t)x], chi[1][(size_t)y], chi[2][(size_t)z]};
+                double c[3], e[3];
+                for (int k = 0; k < 3; ++k) { c[k] = 0.5 * (vlo[k] + vhi[k]); e[k] = 0.5 * (vhi[k] - vlo[k]); }
+                uint64_t *m = &out->masks[(((size_t)z * N[1] + y) * N[0] + x) * RT_SVOX_MAX_LIGHTS];
+                for (int i = first_leaf; i < n_items; ++i) {
+                    double far = 0.0, blo[3], bhi[3];
+                    for (int k = 0; k < 3; ++k) {
+                        blo[k] = items[(size_t)2 * i].v[k];
+                        bhi[k] = items[(size_t)2 * i + 1].v[k];
+                        far += std::max(std::max(std::fabs(blo[k] - vlo[k]), std::fabs(blo[k] - vhi[k])),
+                                        std::max(std::fabs(bhi[k] - vlo[k]), std::fabs(bhi[k] - vhi[k])));
+                    }
+                    const double grow = ((double)RT_SPHERE_SLACK + 1e-5) * far + 1e-5;
+                    for (int k = 0; k < 3; ++k) { blo[k] -= grow; bhi[k] += grow; }
+                    for (int l = 0; l < n_lights; ++l)
+                        if (hull_meets_box(c, e, L[l], blo, bhi)) m[l] |= 1ull << i;
+                }
+            }
+    return true;
 }
 
 /* Build the LDS image + run lists from the stored description. */
@@ -577,6 +737,21 @@ int pack_scene(rt_scene *s) {
     }
     if (image.empty()) image.push_back(Quad{{0, 0, 0, 0}});   /* keep uploads non-empty */
     b.image_quads = (int)image.size();
+    /* SHADOW VOXELS: behind the staged part; read from the global copy by the clustered-scene kernels */
+    b.svox_off = 0;
+    if (!fast && s->cull_opt && s->svox_opt != 0 && n_clusters > 0) {
+        ShadowVoxels sv;
+        /* automatic: from RT_SVOX_MIN_LEAVES leaves on.  With fewer the bundle cull leaves little to take away -- the 256-sphere
+         * grid (16 leaves) at depth 8: 3.8 -> 2.6 candidates per scan, frame 3.94 -> 4.03 ms with the table; the 1 024-sphere grid
+         * (43 leaves): 8.9 -> 4.4, 3.87 -> 3.71 ms (profiles/r04_experiments.txt 8) */
+        if (shadow_voxels(shadow_items, b.shadow_first_leaf, lights, s->svox_opt > 0 ? s->svox_opt : RT_SVOX_MAX_CELLS,
+                          s->svox_opt > 0 ? 4 : RT_SVOX_MIN_LEAVES, &sv)) {
+            b.svox_off = (int)image.size();
+            image.resize(image.size() + (sv.masks.size() + 1) / 2, Quad{{0, 0, 0, 0}});
+            std::memcpy(image[(size_t)b.svox_off].v, sv.masks.data(), sv.masks.size() * 8);
+            for (int k = 0; k < 3; ++k) { b.svox_n[k] = sv.n[k]; b.svox_lo[k] = sv.lo[k]; b.svox_scale[k] = sv.scale[k]; }
+        }
+    }
     b.n_clusters = n_clusters;
     b.n_lights = (int)(lights.size() / RT_LIGHT_QUADS);
     for (int c = 0; c < 3; ++c) b.null_color[c] = s->null_color[c];
@@ -1554,6 +1729,10 @@ int rt_set_option(rt_scene *s, const char *key, int value) {
         return repack_with(s->tables_opt, value);
     }
     if (!std::strcmp(key, "cull")) return repack_with(s->cull_opt, value != 0);
+    if (!std::strcmp(key, "svox")) {
+        if (value < -1 || value > (1 << 20)) return fail(RT_ERR_INVALID, "svox must be -1 (automatic), 0 (no SHADOW VOXELS) or a number of voxels up to 2^20");
+        return repack_with(s->svox_opt, value);
+    }
     if (!std::strcmp(key, "cluster_leaf")) {
         if (value < -1 || value > 255) return fail(RT_ERR_INVALID, "cluster_leaf must be in [0, 255], or -1 (automatic)");
         return repack_with(s->cluster_leaf, value);

@@ -230,62 +230,181 @@ __device__ __forceinline__ void sphere_distance(const float4 s, const V3 o, cons
     }
 }
 
+/* SPHERE TESTS WITHOUT SCALAR INSTRUCTIONS.  A CU of gfx950 issues ONE scalar instruction per cycle for its four SIMDs
+ * (scripts/ubench/issue_rate.hip: 0.87-0.97 s_add or s_and_b64 per CU and cycle with one to eight wavefronts per SIMD, next to
+ * 1.75 vector ones; a 2 : 1 mix of vector and scalar instructions tops out at 1.56 + 0.78), and the sphere-grid frames ran 0.67
+ * scalar instructions + 0.19 branches per CU and cycle next to 1.34 vector ones: the scalar unit was as busy as the vector
+ * pipes.  Most of that came from the reference's accept / reject ladder (src/SceneSphere.cpp:60-116) written with `&&`: every
+ * per-lane condition is a v_cmp into a scalar register pair, every `&&` an s_and_b64, and the nested conditions became
+ * exec-mask branches -- 16 scalar instructions and 4 branches per sphere test.  Here the ladder is arithmetic.  For a finite v
+ * and a finite d^2 (q):
+ *     candidate  <=>  !(v < 0) && !(q < 1e-9)          <=>  min(v, q - 1e-9f) >= 0
+ *                     (a float difference of two floats has the sign of the exact one -- denormals are kept, so it is never
+ *                     rounded to zero --; min skips a NaN operand, which the `!(x < c)` form also accepts)
+ *     root2 > 0:      holds for every candidate (v >= 0, sqrt(q) >= 3e-5)
+ *     the chosen root (root1, or root2 when root1 < 0) < 65535  <=>  65534.99609375f - root >= 0   (the float below 65535)
+ * so a hit is ONE comparison of the minimum of the two margins, and the result -- the reported distance root1, or +infinity
+ * for a miss -- one select.  Lanes that are no candidates may carry a NaN root (q < 0): min skips it and their own margin is
+ * negative.  A wavefront with a lane whose q is not finite or beyond the short square root's range (v not finite implies q not
+ * finite) takes the ladder as written instead (the *_exact routines): overflowing scenes, never the benchmarks'. */
+__device__ __forceinline__ float sphere_margin(const float v, const float q) { return __builtin_fminf(v, q - (float)1E-9); }
+__device__ __forceinline__ float sphere_hit_or_inf(const float v, const float root, const float margin) {
+    const float root1 = v - root, root2 = v + root;
+    const float chosen = (root1 < 0.0f) ? root2 : root1;
+    const float ok = __builtin_fminf(margin, 65534.99609375f - chosen);
+    return (ok >= 0.0f) ? root1 : __builtin_huge_valf();
+}
+/* the ladder as the reference writes it; +infinity for a miss */
+__device__ __forceinline__ float sphere_hit_or_inf_exact(const float v, const float q) {
+    const bool candidate = !(v < (float)0) && !(q < (float)1E-9);
+    const float root = sqrtf(q);
+    const float root1 = v - root, root2 = v + root;
+    const bool ok = (root2 > (float)0) && ((root1 < (float)0) ? (root2 < 65535.0f) : (root1 < 65535.0f));
+    return (candidate && ok) ? root1 : __builtin_huge_valf();
+}
+__device__ __forceinline__ bool sphere_operands_plain(const float q_magnitudes) { return q_magnitudes <= 0x1p+120f; }   /* false for a NaN */
+
+/* SceneSphere::collision reduced to its distance, src/SceneSphere.cpp:50-116: the distance the reference reports (v - sqrt(d^2),
+ * negative for inside hits), or +infinity when it returns NULL */
+__device__ __forceinline__ float sphere_hit_distance(const float4 s, const V3 o, const V3 d) {
+    const V3 OE = mk(s.x - o.x, s.y - o.y, s.z - o.z);
+    const float v = dot3(OE, d);
+    const float q = s.w - (dot3(OE, OE) - v * v);
+    const float margin = sphere_margin(v, q);
+    float t = __builtin_huge_valf();
+    if (wave_any(margin >= 0.0f)) {
+        if (wave_any(!sphere_operands_plain(fabsf(q)))) t = sphere_hit_or_inf_exact(v, q);
+        else t = sphere_hit_or_inf(v, sqrt_in_range(q), margin);
+    }
+    return t;
+}
+
 /* The members of a leaf of a clustered sphere run against a shadow segment: does any of them block?  The tests
- * are sphere_distance()'s, RT_MEMBERS_ABREAST of them side by side: they depend on nothing but the ray, so their
+ * are sphere_hit_distance()'s, RT_MEMBERS_ABREAST of them side by side: they depend on nothing but the ray, so their
  * dependency chains (LDS read, ~20 dependent operations, the square root's sequence) overlap instead of queueing
  * up -- a wavefront that scans the whole field for all of its rays (the horizon tiles) is bound by exactly that
- * chain.  Blocking is an OR, so the grouping cannot change the result. */
+ * chain.  Blocking is an OR -- here: the minimum of the reported distances against the distance to the light --, so the
+ * grouping cannot change the result, and testing a sphere twice cannot either (callers pass any valid sphere for a member
+ * that does not exist). */
 #ifndef RT_MEMBERS_ABREAST
 #define RT_MEMBERS_ABREAST 4
 #endif
-/* four sphere tests side by side: does any of the valid ones block the segment? */
-__device__ __forceinline__ bool four_spheres_block(const float4 s0, const float4 s1, const float4 s2, const float4 s3,
-                                                   const V3 o, const V3 d, const float dist_to_light,
-                                                   const bool k0, const bool k1, const bool k2, const bool k3) {
-    const V3 e0 = mk(s0.x - o.x, s0.y - o.y, s0.z - o.z), e1 = mk(s1.x - o.x, s1.y - o.y, s1.z - o.z);
-    const V3 e2 = mk(s2.x - o.x, s2.y - o.y, s2.z - o.z), e3 = mk(s3.x - o.x, s3.y - o.y, s3.z - o.z);
-    const float v0 = dot3(e0, d), v1 = dot3(e1, d), v2 = dot3(e2, d), v3 = dot3(e3, d);
-    const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);
-    const float q2 = s2.w - (dot3(e2, e2) - v2 * v2), q3 = s3.w - (dot3(e3, e3) - v3 * v3);
-    /* `if (v < 0) return NULL; ... if (d_squared < 1E-9) return NULL;`, as in sphere_distance() */
-    const bool c0 = k0 && !(v0 < (float)0) && !(q0 < (float)1E-9), c1 = k1 && !(v1 < (float)0) && !(q1 < (float)1E-9);
-    const bool c2 = k2 && !(v2 < (float)0) && !(q2 < (float)1E-9), c3 = k3 && !(v3 < (float)0) && !(q3 < (float)1E-9);
-    bool any = false;
-    if (wave_any(c0 || c1 || c2 || c3)) {
-        float r0, r1, r2, r3;
-        if (wave_any((c0 && !(q0 <= 0x1p+120f)) || (c1 && !(q1 <= 0x1p+120f)) || (c2 && !(q2 <= 0x1p+120f)) || (c3 && !(q3 <= 0x1p+120f)))) {
-            r0 = sqrtf(q0); r1 = sqrtf(q1); r2 = sqrtf(q2); r3 = sqrtf(q3);
-        } else {                                              /* candidates have q >= 1e-9: the short square root's range */
-            r0 = sqrt_in_range(q0); r1 = sqrt_in_range(q1); r2 = sqrt_in_range(q2); r3 = sqrt_in_range(q3);
-        }
-        const float a0 = v0 - r0, b0 = v0 + r0, a1 = v1 - r1, b1 = v1 + r1, a2 = v2 - r2, b2 = v2 + r2, a3 = v3 - r3, b3 = v3 + r3;
-        const bool h0 = c0 && (b0 > (float)0) && ((a0 < (float)0) ? (b0 < 65535.0f) : (a0 < 65535.0f)) && a0 < dist_to_light;
-        const bool h1 = c1 && (b1 > (float)0) && ((a1 < (float)0) ? (b1 < 65535.0f) : (a1 < 65535.0f)) && a1 < dist_to_light;
-        const bool h2 = c2 && (b2 > (float)0) && ((a2 < (float)0) ? (b2 < 65535.0f) : (a2 < 65535.0f)) && a2 < dist_to_light;
-        const bool h3 = c3 && (b3 > (float)0) && ((a3 < (float)0) ? (b3 < 65535.0f) : (a3 < 65535.0f)) && a3 < dist_to_light;
-        any = h0 || h1 || h2 || h3;
+/* four sphere tests side by side: the smallest distance any of them reports (+infinity: none hit), from the tests' v, q (= d^2)
+ * and margins */
+__device__ __forceinline__ float four_spheres_nearest_vq(const float v0, const float v1, const float v2, const float v3,
+                                                         const float q0, const float q1, const float q2, const float q3,
+                                                         const float m0, const float m1, const float m2, const float m3) {
+    float t0, t1, t2, t3;
+    if (wave_any(!sphere_operands_plain((fabsf(q0) + fabsf(q1)) + (fabsf(q2) + fabsf(q3))))) {
+        t0 = sphere_hit_or_inf_exact(v0, q0); t1 = sphere_hit_or_inf_exact(v1, q1);
+        t2 = sphere_hit_or_inf_exact(v2, q2); t3 = sphere_hit_or_inf_exact(v3, q3);
+    } else {
+        const float r0 = sqrt_in_range(q0), r1 = sqrt_in_range(q1), r2 = sqrt_in_range(q2), r3 = sqrt_in_range(q3);
+        t0 = sphere_hit_or_inf(v0, r0, m0); t1 = sphere_hit_or_inf(v1, r1, m1);
+        t2 = sphere_hit_or_inf(v2, r2, m2); t3 = sphere_hit_or_inf(v3, r3, m3);
     }
-    return any;
+    return __builtin_fminf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3));
+}
+
+#define RT_FOUR_SPHERES_VQ(s0, s1, s2, s3, o, d)                                                                            \
+    const V3 e0 = mk(s0.x - o.x, s0.y - o.y, s0.z - o.z), e1 = mk(s1.x - o.x, s1.y - o.y, s1.z - o.z);                     \
+    const V3 e2 = mk(s2.x - o.x, s2.y - o.y, s2.z - o.z), e3 = mk(s3.x - o.x, s3.y - o.y, s3.z - o.z);                     \
+    const float v0 = dot3(e0, d), v1 = dot3(e1, d), v2 = dot3(e2, d), v3 = dot3(e3, d);                                    \
+    const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);                                \
+    const float q2 = s2.w - (dot3(e2, e2) - v2 * v2), q3 = s3.w - (dot3(e3, e3) - v3 * v3);                                \
+    const float m0 = sphere_margin(v0, q0), m1 = sphere_margin(v1, q1), m2 = sphere_margin(v2, q2), m3 = sphere_margin(v3, q3)
+
+__device__ __forceinline__ float four_spheres_nearest(const float4 s0, const float4 s1, const float4 s2, const float4 s3,
+                                                      const V3 o, const V3 d) {
+    RT_FOUR_SPHERES_VQ(s0, s1, s2, s3, o, d);
+    float nearest = __builtin_huge_valf();
+    /* (max skips a NaN margin -- a lane with v and q both NaN, which hits nothing) */
+    if (wave_any(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)) >= 0.0f))
+        nearest = four_spheres_nearest_vq(v0, v1, v2, v3, q0, q1, q2, q3, m0, m1, m2, m3);
+    return nearest;
+}
+
+/* BLOCKED WITHOUT THE SQUARE ROOT.  A shadow scan does not want the distance a sphere reports, only whether it is below the
+ * distance to the light (src/RayTracer.cpp:727-729), and for nearly every sphere that a shadow ray meets that is plain from v:
+ * the reported distance is root1 = fl(v - sqrt(q)) <= v, so a candidate (margin >= 0) with
+ *     v <= limit,   limit = min(fl(dist * (1 - 2^-20)), 3e4) < dist   (-infinity when dist is a NaN: nothing is below a NaN)
+ *     q <= 1e9      (then root2 = fl(v + sqrt(q)) <= 3e4 + 31 623 < 65535: the reference's "< 65535" holds for either root)
+ * is a hit with root1 < dist whatever the square root's digits are.  `blocked` is kept as a number: >= 0 <=> blocked, and a test
+ * adds to it by a maximum -- the least of the three margins.  Only a candidate that is not plainly blocking (its nearest point
+ * to the centre lies beyond the light) on a ray that nothing has blocked yet needs the square root: then, and for operands that
+ * are not finite, the four are evaluated as four_spheres_nearest() does.  14 vector instructions per sphere fewer (the square
+ * root's nine and the ladder's) on all but a few per cent of the tests. */
+struct ShadowRay { float dist, limit; };
+__device__ __forceinline__ ShadowRay shadow_ray(const float dist_to_light) {
+    ShadowRay r;
+    r.dist = dist_to_light;
+    r.limit = (dist_to_light == dist_to_light) ? __builtin_fminf(dist_to_light * 0.99999905f, 3.0e4f) : -__builtin_huge_valf();
+    return r;
+}
+__device__ __forceinline__ float blocked_number(const bool blocked) { return blocked ? 1.0f : -1.0f; }     /* (not 0: -0 >= 0 would read as "not yet") */
+
+__device__ __forceinline__ float four_spheres_block(const float4 s0, const float4 s1, const float4 s2, const float4 s3,
+                                                    const V3 o, const V3 d, const ShadowRay ray, float blocked) {
+    RT_FOUR_SPHERES_VQ(s0, s1, s2, s3, o, d);
+    const float candidate = __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3));
+    /* nothing to do unless some ray that is not blocked yet has a candidate among the four (a NaN margin -- v and q both NaN:
+     * no hit -- is skipped by the maximum, or passes and is sorted out by the exact tests) */
+    if (wave_any(__builtin_fminf(candidate, -blocked) >= 0.0f)) {
+        const float u0 = __builtin_fminf(m0, __builtin_fminf(ray.limit - v0, 1.0e9f - q0));
+        const float u1 = __builtin_fminf(m1, __builtin_fminf(ray.limit - v1, 1.0e9f - q1));
+        const float u2 = __builtin_fminf(m2, __builtin_fminf(ray.limit - v2, 1.0e9f - q2));
+        const float u3 = __builtin_fminf(m3, __builtin_fminf(ray.limit - v3, 1.0e9f - q3));
+        /* (with operands that are not finite the margins mean nothing: the lane's verdict then comes from the exact tests) */
+        const bool plain = sphere_operands_plain((fabsf(q0) + fabsf(q1)) + (fabsf(q2) + fabsf(q3)));
+        const float sure = __builtin_fmaxf(__builtin_fmaxf(u0, u1), __builtin_fmaxf(u2, u3));
+        blocked = plain ? __builtin_fmaxf(blocked, sure) : blocked;
+        /* still not blocked, with a candidate that did not settle it -- or operands that are not plain numbers */
+        if (wave_any(!plain || __builtin_fminf(candidate, -blocked) >= 0.0f)) {
+            const float nearest = four_spheres_nearest_vq(v0, v1, v2, v3, q0, q1, q2, q3, m0, m1, m2, m3);
+            blocked = (nearest < ray.dist) ? 1.0f : blocked;
+        }
+    }
+    return blocked;
+}
+
+/* one sphere, the same way */
+__device__ __forceinline__ float sphere_blocks(const float4 s, const V3 o, const V3 d, const ShadowRay ray, float blocked) {
+    const V3 OE = mk(s.x - o.x, s.y - o.y, s.z - o.z);
+    const float v = dot3(OE, d);
+    const float q = s.w - (dot3(OE, OE) - v * v);
+    const float m = sphere_margin(v, q);
+    if (wave_any(__builtin_fminf(m, -blocked) >= 0.0f)) {
+        const float u = __builtin_fminf(m, __builtin_fminf(ray.limit - v, 1.0e9f - q));
+        const bool plain = sphere_operands_plain(fabsf(q));
+        blocked = plain ? __builtin_fmaxf(blocked, u) : blocked;
+        if (wave_any(!plain || __builtin_fminf(m, -blocked) >= 0.0f)) {
+            float t;
+            if (wave_any(!plain)) t = sphere_hit_or_inf_exact(v, q);
+            else t = sphere_hit_or_inf(v, sqrt_in_range(q), m);
+            blocked = (t < ray.dist) ? 1.0f : blocked;
+        }
+    }
+    return blocked;
 }
 
 template <bool kStats, bool kAbreast>
 __device__ __forceinline__ bool leaf_members_block(const float4 *g, const int n, const V3 o, const V3 d, const float dist_to_light,
-                                                   const bool lane_needs, bool blocked, Stats<kStats> &st) {
+                                                   const bool lane_needs, const bool blocked_in, Stats<kStats> &st) {
     int i = 0;
+    const ShadowRay ray = shadow_ray(dist_to_light);
+    float blocked = blocked_number(blocked_in);
     if constexpr (kAbreast && RT_MEMBERS_ABREAST == 4) {      /* not in the plain kernel: its 72 registers do not hold four tests */
         for (; i + 4 <= n; i += 4) {
             if constexpr (kStats) { for (int k = 0; k < 4; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs); } }
-            blocked = blocked || four_spheres_block(g[i], g[i + 1], g[i + 2], g[i + 3], o, d, dist_to_light, true, true, true, true);
+            blocked = four_spheres_block(g[i], g[i + 1], g[i + 2], g[i + 3], o, d, ray, blocked);
         }
     }
 #pragma unroll 2
     for (; i < n; ++i) {
-        bool hit; float t;
         st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
-        sphere_distance(g[i], o, d, &hit, &t);
-        blocked = blocked || (hit && t < dist_to_light);
+        blocked = sphere_blocks(g[i], o, d, ray, blocked);
     }
-    return blocked;
+    return blocked >= 0.0f;
 }
 
 /* Plane prefilter shared by both plane kinds.  t = numerator / denom is only
@@ -510,6 +629,38 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k) {
     return (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
 }
 
+/* Wavefront-wide OR of two 64-bit per-lane values given as four words (all 64 lanes active): four chains side by side, like
+ * wave_bounds3()'s six */
+__device__ __forceinline__ void wave_or_u64x2(uint32_t a_lo, uint32_t a_hi, uint32_t b_lo, uint32_t b_hi,
+                                              unsigned long long *a, unsigned long long *b) {
+#define RT_DPP_STEP(ctrl) "v_or_b32_dpp %0, %0, %0 " ctrl "\n v_or_b32_dpp %1, %1, %1 " ctrl "\n v_or_b32_dpp %2, %2, %2 " ctrl "\n v_or_b32_dpp %3, %3, %3 " ctrl "\n"
+    asm volatile("s_nop 1\n"
+                 RT_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 RT_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 RT_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n"
+                 : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi));
+#undef RT_DPP_STEP
+    *a = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)a_lo, 63) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)a_hi, 63) << 32);
+    *b = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b_lo, 63) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b_hi, 63) << 32);
+}
+
+/* SHADOW VOXELS (rt_tables.h): the cell of u = (x - lo) * scale on one axis of the grid -- RT_SVOX_TAIL cells below the core,
+ * n core cells, RT_SVOX_TAIL above; -1: beyond the last cell, or a NaN.  Tail cell j holds the points whose distance d beyond
+ * the core, in core cells, has 16^j <= 1 + 15 d < 16^(j+1): j = floor(log16) from the float's exponent.  svox_axis_bounds()
+ * (rt_capi.hip) widens every cell by more than these roundings can move a point. */
+__device__ __forceinline__ int svox_axis_cell(const float u, const int n) {
+    const float fn = (float)n;
+    const bool core = u >= 0.0f && u < fn;
+    const float d = u < 0.0f ? -u : u - fn;
+    const float w = d * 15.0f + 1.0f;
+    const int j = ((int)(__float_as_uint(w) >> 23) - 127) >> 2;
+    const bool tail = w >= 1.0f && j < RT_SVOX_TAIL;           /* (a NaN fails the comparison; infinity has j = 32) */
+    return core ? RT_SVOX_TAIL + (int)u : (tail ? (u < 0.0f ? RT_SVOX_TAIL - 1 - j : RT_SVOX_TAIL + n + j) : -1);
+}
 
 /* getCollision (src/RayTracer.cpp:50-89) over the ITEM table with a
  * wave-cooperative cull -- the nearest-hit counterpart of in_shade() below.
@@ -536,6 +687,15 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k) {
  * of equals, src/RayTracer.cpp:71-80). */
 __device__ __forceinline__ bool nearer(const float t, const int idx, const float best, const int best_idx) {
     return t < best || (t == best && idx < best_idx);
+}
+/* (best, best_idx) := the earlier of it and (t, idx) in that order, without a branch or a scalar instruction (SPHERE TESTS
+ * WITHOUT SCALAR INSTRUCTIONS, above): t is a reported distance or +infinity, never a NaN; best_idx = -1 (nothing yet) goes
+ * with best = 65535, which no reported distance reaches */
+__device__ __forceinline__ void take_nearer(const float t, const int idx, float *best, int *best_idx) {
+    const int on_tie = min(idx, *best_idx);
+    const int kept = (t == *best) ? on_tie : *best_idx;
+    *best_idx = (t < *best) ? idx : kept;
+    *best = __builtin_fminf(*best, t);
 }
 
 /* The bundle cull of nearest_hit_items() asks, per axis, for the t >= 0 with
@@ -720,20 +880,17 @@ __device__ __forceinline__ void flush_near_pairs(const float4 *lds, NearPairs &p
     const V3 po = mk(lane_pull_f(from, o.x), lane_pull_f(from, o.y), lane_pull_f(from, o.z));
     const V3 pd = mk(lane_pull_f(from, d.x), lane_pull_f(from, d.y), lane_pull_f(from, d.z));
     const int rot = count == 16 ? ((geom >> 4) & 15) : 0;
+    const int members = has ? count : 0;                  /* of this slot's leaf; none without a pair */
     float pair_t = 65535.0f;
     int pair_idx = -1;
-    for (int i = 0; wave_any(has && i < count); ++i) {
+    for (int i = 0; wave_any(i < members); ++i) {
         int j = i + rot;
         j = j >= count ? j - count : j;
-        bool hit; float t;
-        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < count);
+        st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i < members);
         st_wave(st, ST_NEAREST_SPHERE);
-        sphere_distance(lds[geom + j], po, pd, &hit, &t);
-        hit = hit && has && i < count;
-        if (wave_any(hit)) {
-            const int member = (int)lds_u32[pb.ids + j];
-            if (hit && nearer(t, member, pair_t, pair_idx)) { pair_t = t; pair_idx = member; }
-        }
+        float t = sphere_hit_distance(lds[geom + j], po, pd);
+        t = (i < members) ? t : __builtin_huge_valf();
+        if (wave_any(t <= pair_t)) take_nearer(t, (int)lds_u32[pb.ids + j], &pair_t, &pair_idx);
     }
     /* back to the rays' lanes, push by push */
     float best = *best_io;
@@ -864,8 +1021,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             bool hit; float t;
             if (kind == RT_KIND_SPHERE) {
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, active);
-                sphere_distance(g[0], o, d, &hit, &t);
-                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
+                take_nearer(sphere_hit_distance(g[0], o, d), idx, &best, &best_idx);
             } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run; bits1 = its members' Scene indices */
                 const int n = (int)((bits >> 8) & 255u);
                 st_wave(st, ST_WAVE_BOX_TESTS);
@@ -893,11 +1049,8 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 for (int i = 0; i < n; ++i) {
                     st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
                     st_wave(st, ST_NEAREST_SPHERE); if (stat_unculled) st_wave(st, ST_NEAREST_UNCULLED_SPHERE);
-                    sphere_distance(g[i], o, d, &hit, &t);
-                    if (wave_any(hit)) {
-                        const int member = (int)ids[i];
-                        if (hit && nearer(t, member, best, best_idx)) { best = t; best_idx = member; }
-                    }
+                    t = sphere_hit_distance(g[i], o, d);
+                    if (wave_any(t <= best)) take_nearer(t, (int)ids[i], &best, &best_idx);
                 }
             } else if (kind == RT_KIND_INFINITE_PLANE) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
@@ -999,28 +1152,28 @@ __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPair
     const V3 pd = mk(lane_pull_f(from, d.x), lane_pull_f(from, d.y), lane_pull_f(from, d.z));
     const float pdist = lane_pull_f(from, dist_to_light);
     const int rot = count == 16 ? ((geom >> 4) & 15) : 0;
-    bool pair_blocked = false;
+    /* (a member number past the leaf's end reads the leaf's first member instead: testing a sphere twice changes nothing) */
+    const int members = has ? count : 0;
+    const ShadowRay ray = shadow_ray(pdist);
+    float pair_verdict = has ? -1.0f : 1.0f;                 /* >= 0: this pair blocks (four_spheres_block()); a slot without a pair asks for nothing */
     if constexpr (kAbreast && RT_MEMBERS_ABREAST == 4) {     /* four members side by side (leaf_members_block()), where the registers allow */
-        for (int i = 0; wave_any(has && i < count); i += 4) {
+        for (int i = 0; wave_any(i < members); i += 4) {
             int j0 = i + rot, j1 = i + 1 + rot, j2 = i + 2 + rot, j3 = i + 3 + rot;
             j0 = j0 >= count ? j0 - count : j0; j1 = j1 >= count ? j1 - count : j1;
             j2 = j2 >= count ? j2 - count : j2; j3 = j3 >= count ? j3 - count : j3;
-            const bool k0 = has && i < count, k1 = has && i + 1 < count, k2 = has && i + 2 < count, k3 = has && i + 3 < count;
-            if constexpr (kStats) { for (int k = 0; k < 4; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i + k < count); } }
-            /* a member index past the leaf's end (k false) reads the leaf's first member instead: any valid quad will do */
-            pair_blocked = pair_blocked || four_spheres_block(lds[geom + (k0 ? j0 : 0)], lds[geom + (k1 ? j1 : 0)], lds[geom + (k2 ? j2 : 0)],
-                                                              lds[geom + (k3 ? j3 : 0)], po, pd, pdist, k0, k1, k2, k3);
+            if constexpr (kStats) { for (int k = 0; k < 4; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i + k < members); } }
+            pair_verdict = four_spheres_block(lds[geom + (i < count ? j0 : 0)], lds[geom + (i + 1 < count ? j1 : 0)],
+                                              lds[geom + (i + 2 < count ? j2 : 0)], lds[geom + (i + 3 < count ? j3 : 0)], po, pd, ray, pair_verdict);
         }
     } else {
-        for (int i = 0; wave_any(has && i < count); ++i) {
+        for (int i = 0; wave_any(i < members); ++i) {
             int j = i + rot;
             j = j >= count ? j - count : j;
-            bool hit; float t;
-            st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, has && i < count);
-            sphere_distance(lds[geom + j], po, pd, &hit, &t);
-            pair_blocked = pair_blocked || (has && i < count && hit && t < pdist);
+            st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i < members);
+            pair_verdict = sphere_blocks(lds[geom + (i < count ? j : 0)], po, pd, ray, pair_verdict);
         }
     }
+    const bool pair_blocked = has && pair_verdict >= 0.0f;
     /* the verdicts, back to the rays' lanes (few pairs block) */
     unsigned long long verdicts = __builtin_amdgcn_ballot_w64(pair_blocked);
     while (verdicts != 0ull) {
@@ -1035,7 +1188,8 @@ __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPair
 template <bool kStats, int kMode>
 __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, float4 *wlds, float4 *help_rays, const bool active,
                                          const V3 o, const V3 d, const float dist_to_light, const V3 light,
-                                         const V3 origins_centre, const V3 origins_half, Stats<kStats> &st) {
+                                         const V3 origins_centre, const V3 origins_half,
+                                         const unsigned long long voxels_say, Stats<kStats> &st) {
     constexpr bool kPairs = kMode != 0;
     constexpr bool kHelped = kMode == 4 || kMode == 5;      /* a first-pass tile of a clustered scene: HELP */
     constexpr bool kRoomy = kMode == 5;                     /* the kernel with registers to spare: the pair flush tests four members abreast */
@@ -1090,6 +1244,11 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
         } else {
             const int left = p.n_shadow_items - base;
             mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        }
+        /* SHADOW VOXELS (rt_tables.h): what the lanes' voxels say can block a segment towards this light at all -- the bundle
+         * is one box around all 64 shading points, the voxels follow each of them (one round: at most 64 shadow items) */
+        if constexpr (kHelped) {
+            mask &= voxels_say;
         }
         if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
         if (kHelped && p.n_clusters > 0) {
@@ -1163,8 +1322,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             bool hit; float t;
             if (kind == RT_KIND_SPHERE) {
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, !blocked);
-                sphere_distance(g[0], o, d, &hit, &t);
-                blocked = blocked || (hit && t < dist_to_light);
+                blocked = sphere_blocks(g[0], o, d, shadow_ray(dist_to_light), blocked_number(blocked)) >= 0.0f;
             } else if (kind == RT_KIND_SPHERE_LEAF) {               /* a leaf of a clustered run */
                 /* one leaf whose box test is done: its (ray, leaf) pairs into the buffer, or its members for the whole wavefront */
                 auto take_leaf = [&](const uint32_t leaf_bits, const bool lane_needs, const unsigned long long needers) {
@@ -1596,6 +1754,33 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
         const unsigned long long t_lights = st_clock<kStats>();
         if (shade) C = mk(0.0f, 0.0f, 0.0f);
         if (wave_any(shade)) {
+            /* SHADOW VOXELS (rt_tables.h): which shadow items can matter to this lane's segments towards the (at most two) lights,
+             * from the voxel its shading point lies in.  A lane outside the grid (or with a NaN: it fails every comparison) says
+             * "any", a lane without a shadow ray "none".  Asked for here, before the bundle's reductions below: the answers are
+             * ORed over the wavefront after them, into two scalars the scans AND into their candidates. */
+            uint4 voxel_masks = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (kMode == 4 || kMode == 5) {
+                if (p.svox_off != 0) {
+                    const float ux = (P.x - p.svox_lo[0]) * p.svox_scale[0];
+                    const float uy = (P.y - p.svox_lo[1]) * p.svox_scale[1];
+                    const float uz = (P.z - p.svox_lo[2]) * p.svox_scale[2];
+                    const bool core = ux >= 0.0f && ux < (float)p.svox_n[0] && uy >= 0.0f && uy < (float)p.svox_n[1] &&
+                                      uz >= 0.0f && uz < (float)p.svox_n[2];
+                    int cx = RT_SVOX_TAIL + (int)ux, cy = RT_SVOX_TAIL + (int)uy, cz = RT_SVOX_TAIL + (int)uz;
+                    bool in_grid = core;
+                    if (wave_any(shade && !core)) {                 /* the cells beyond the core: only where somebody needs them */
+                        cx = svox_axis_cell(ux, p.svox_n[0]); cy = svox_axis_cell(uy, p.svox_n[1]); cz = svox_axis_cell(uz, p.svox_n[2]);
+                        in_grid = (cx | cy | cz) >= 0;
+                    }
+#ifndef RT_SVOX_UNSAFE_OUTSIDE                               /* (EXPERIMENT ONLY when defined: lanes outside the grid ask for nothing -- wrong pixels) */
+                    if (shade) voxel_masks = make_uint4(~0u, ~0u, ~0u, ~0u);
+#endif
+                    if (shade && in_grid) {
+                        const int voxel = (cz * (p.svox_n[1] + 2 * RT_SVOX_TAIL) + cy) * (p.svox_n[0] + 2 * RT_SVOX_TAIL) + cx;
+                        voxel_masks = (reinterpret_cast<const uint4 *>(ctl_words) + (size_t)p.svox_off)[voxel];
+                    }
+                }
+            }
             /* box of the shading points, shared by every light's shadow scan */
             V3 bundle_centre = mk(0, 0, 0), bundle_half = bundle_centre;
             if constexpr (kMode == 6) {          /* FAST tables: the culls always run */
@@ -1613,9 +1798,14 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
              * identity -- N.N rounds to exactly 1 in every shading lane, the usual case -- does not depend on the light:
              * asked once per level here instead of twice per light there. */
             const bool normals_are_unit = !wave_any(shade && (N.x * N.x + N.y * N.y + N.z * N.z) != 1.0f);
+            unsigned long long voxels_say0 = ~0ull, voxels_say1 = ~0ull;       /* bit i: shadow item i can matter to some lane's segment towards light 0 / 1 */
+            if constexpr (kMode == 4 || kMode == 5) {
+                if (p.svox_off != 0) wave_or_u64x2(voxel_masks.x, voxel_masks.y, voxel_masks.z, voxel_masks.w, &voxels_say0, &voxels_say1);
+            }
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
+                const unsigned long long voxels_say = l == 0 ? voxels_say0 : (l == 1 ? voxels_say1 : ~0ull);
                 /* inShade, :743-771 */
                 const V3 dir = sub3(xyz(l0), P);
                 float dist_to_light;                         /* |dir|, :748 -- the length normalize3() takes the root of anyway */
@@ -1623,7 +1813,8 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                 const unsigned long long t_shadow = st_clock<kStats>();
                 bool blocked;
                 if constexpr (kMode == 6) blocked = in_shade_fast<kStats>(p, lds, ctl_words, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
-                else blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
+                else blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half,
+                                                       voxels_say, st);
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
                 if (shade && !blocked) {
                     /* the winner's material, re-read here rather than kept in registers across the shadow scan */

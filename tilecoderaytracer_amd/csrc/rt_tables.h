@@ -122,6 +122,22 @@ enum { RT_DESK_STATE = 0, RT_DESK_CURSOR, RT_DESK_INSIDE, RT_DESK_FINISHED, RT_D
 
 #define RT_PRIMARY_ITEMS 64          /* scenes with more FAST items than this have no PRIMARY table */
 
+/* relative growth of a leaf's box that must contain every member sphere the reference's float arithmetic can report from a
+ * given origin (derived at box_needed(), rt_kernel.hip); the host's SHADOW VOXELS use the same figure */
+#ifndef RT_SPHERE_SLACK
+#define RT_SPHERE_SLACK 1.5e-3f
+#endif
+/* SHADOW VOXELS (below): at most this many voxels, lights and shadow items */
+#ifndef RT_SVOX_MAX_CELLS
+#define RT_SVOX_MAX_CELLS 4096
+#endif
+/* cells beyond the core, per axis and side: cell j holds the points whose distance d beyond the core, in core cells, has
+ * 16^j <= 1 + 15 d < 16^(j+1) -- four cells reach 4 369 core cells out; further away every item may matter anyway */
+#define RT_SVOX_TAIL 4
+#define RT_SVOX_MAX_LIGHTS 2        /* one quad per voxel: a 64-bit mask per light */
+#define RT_SVOX_MAX_ITEMS 64
+#define RT_SVOX_MIN_LEAVES 24        /* automatic: scenes with fewer leaves get no table (option "svox" n: from 4 leaves on) */
+
 typedef struct RtParams {
     /* camera (src/Camera.cpp:71-84) */
     float so[3], ch[3], cv[3], eye[3];
@@ -169,6 +185,19 @@ typedef struct RtParams {
      * primary_off = its place in LDS (quads, behind the image; one quad per item: {x_lo | x_hi << 16 (int16 pixels),
      * z_lo | z_hi << 16, bits of the entry distance, 0}). */
     int32_t n_primary, primary_off;
+    /* SHADOW VOXELS (scenes with clustered sphere runs, at most RT_SVOX_MAX_ITEMS shadow items and RT_SVOX_MAX_LIGHTS lights;
+     * rt_capi.hip: shadow_voxels(); option "svox").  A grid of svox_n[0] x [1] x [2] voxels over the part of space the leaves
+     * occupy (the core), continued on every axis and side by RT_SVOX_TAIL cells that grow 16-fold each (N = n + 2 RT_SVOX_TAIL
+     * cells per axis); per voxel and light one 64-bit mask: bit i set = shadow item i can block the segment from SOME
+     * point of the voxel to that light (plain items: always set; a leaf: its box, grown by the slack the float sphere test needs
+     * from anywhere in the voxel, meets the hull of voxel and light).  A shadow scan ORs the masks of its lanes' voxels (a lane
+     * outside the grid: all ones) and ANDs the result into the candidates its bundle cull left: the bundle is one box around
+     * all 64 shading points, the voxels follow each ray.  svox_off = quad offset of the table in the image's GLOBAL copy, behind
+     * the part that is staged into LDS (0: no table); one quad per voxel (light 0's mask, light 1's), voxel = (z * Ny + y) * Nx + x, the
+     * per-axis cell numbers as svox_axis_cell() (rt_kernel.hip) finds them from (P.k - svox_lo[k]) * svox_scale[k] */
+    int32_t svox_off;
+    int32_t svox_n[3];
+    float svox_lo[3], svox_scale[3];
     uint32_t primary[RT_PRIMARY_ITEMS * 4];
     /* one word of host memory the kernel can write (rt_scene's sticky device error): set when a HELP wait timed out */
     uint64_t error_word;
