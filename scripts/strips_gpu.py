@@ -19,16 +19,19 @@ for name, d in [("builtin", 4), ("grid32", 4), ("grid16", 8), ("grid32-noshadow"
     buf = torch.empty((S, S, 3), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     LEARN = "learn=1" in sys.argv[1:]                  # learn=1: rt_learn_tile_order for every strip before it is timed
-    def t(x0, x1, n=3):
+    def t(x0, x1, n=6):
         if LEARN and (x0, x1) != (0, S):
             r.learn_tile_order(S, S, d, x0, x1)
-        r.render_device(S, S, d, x0, x1, buf.data_ptr(), st); torch.cuda.synchronize()
+        for _ in range(3):                      # (a process's first launches run on clocks that are still rising)
+            r.render_device(S, S, d, x0, x1, buf.data_ptr(), st)
+        torch.cuda.synchronize()
         r.reset_timing()
         for _ in range(n):
             r.render_device(S, S, d, x0, x1, buf.data_ptr(), st)
         torch.cuda.synchronize()
         tm = r.timing()
         return tm.sum_kernel_ms / tm.launches
+    t(0, S)
     full = t(0, S)
     for N in NS:
         ts = [t(*strip_bounds(S, N, k)[:2]) for k in range(N)]

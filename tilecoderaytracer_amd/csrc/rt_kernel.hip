@@ -207,29 +207,6 @@ template <> __device__ __forceinline__ void st_maxlane<true>(Stats<true> &st, in
     st.c[k] += ((threadIdx.x & 63u) == 0u) ? (unsigned int)most : 0u;
 }
 
-/* SceneSphere::collision reduced to its distance, src/SceneSphere.cpp:50-116.
- * *hit is true when the reference would return a CollisionObject; *dist is
- * then the distance it reports (v - sqrt(d^2), negative for inside hits). */
-__device__ __forceinline__ void sphere_distance(const float4 s, const V3 o, const V3 d, bool *hit, float *dist) {
-    const V3 OE = mk(s.x - o.x, s.y - o.y, s.z - o.z);
-    const float v = dot3(OE, d);
-    const float d_squared = s.w - (dot3(OE, OE) - v * v);
-    /* `if (v < 0) return NULL; ... if (d_squared < 1E-9) return NULL;` */
-    const bool candidate = !(v < (float)0) && !(d_squared < (float)1E-9);
-    *hit = false;
-    *dist = 0.0f;
-    if (wave_any(candidate)) {
-        /* candidates have d_squared >= 1e-9: in the short square root's range unless it is huge */
-        const float sq = wave_any(candidate && !(d_squared <= 0x1p+120f)) ? sqrtf(d_squared) : sqrt_in_range(d_squared);
-        const float root1 = v - sq;
-        const float root2 = v + sq;
-        /* the root2 > 0 / root1 < 0 / "< 65535" ladder of :93-116 */
-        const bool ok = (root2 > (float)0) && ((root1 < (float)0) ? (root2 < 65535.0f) : (root1 < 65535.0f));
-        *hit = candidate && ok;
-        *dist = root1;
-    }
-}
-
 /* SPHERE TESTS WITHOUT SCALAR INSTRUCTIONS.  A CU of gfx950 issues ONE scalar instruction per cycle for its four SIMDs
  * (scripts/ubench/issue_rate.hip: 0.87-0.97 s_add or s_and_b64 per CU and cycle with one to eight wavefronts per SIMD, next to
  * 1.75 vector ones; a 2 : 1 mix of vector and scalar instructions tops out at 1.56 + 0.78), and the sphere-grid frames ran 0.67
@@ -313,16 +290,6 @@ __device__ __forceinline__ float four_spheres_nearest_vq(const float v0, const f
     const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);                                \
     const float q2 = s2.w - (dot3(e2, e2) - v2 * v2), q3 = s3.w - (dot3(e3, e3) - v3 * v3);                                \
     const float m0 = sphere_margin(v0, q0), m1 = sphere_margin(v1, q1), m2 = sphere_margin(v2, q2), m3 = sphere_margin(v3, q3)
-
-__device__ __forceinline__ float four_spheres_nearest(const float4 s0, const float4 s1, const float4 s2, const float4 s3,
-                                                      const V3 o, const V3 d) {
-    RT_FOUR_SPHERES_VQ(s0, s1, s2, s3, o, d);
-    float nearest = __builtin_huge_valf();
-    /* (max skips a NaN margin -- a lane with v and q both NaN, which hits nothing) */
-    if (wave_any(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)) >= 0.0f))
-        nearest = four_spheres_nearest_vq(v0, v1, v2, v3, q0, q1, q2, q3, m0, m1, m2, m3);
-    return nearest;
-}
 
 /* BLOCKED WITHOUT THE SQUARE ROOT.  A shadow scan does not want the distance a sphere reports, only whether it is below the
  * distance to the light (src/RayTracer.cpp:727-729), and for nearly every sphere that a shadow ray meets that is plain from v:
@@ -498,6 +465,81 @@ __device__ __forceinline__ void aa_rectangle_distance(const float4 r0, const flo
 }
 
 
+/* PLANE TESTS WITHOUT SCALAR INSTRUCTIONS (the FAST scans; see SPHERE TESTS WITHOUT SCALAR INSTRUCTIONS above for why).  The
+ * same tests as plane_candidate() / infinite_plane_distance() / aa_rectangle_distance() / finite_plane_distance(), with every
+ * accept / reject condition written as a MARGIN (>= 0: passes) and the conditions combined by minima: one comparison and one
+ * select per test where the `&&` / `||` forms take a v_cmp per condition and an s_and / s_or per operator.  The result is the
+ * distance the reference reports, or +infinity for a miss.
+ *   x > 0   <=>  x - 0x1p-149f >= 0   (denormals are kept: the smallest one is representable)
+ *   x <= c  <=>  c - x >= 0, x < c <=> pred(c) - x >= 0: a float difference of floats has the sign of the exact one
+ *   numerator and denominator non-zero with equal signs  <=>  min(numerator * copysign(1, denom), |denom|) > 0
+ * min / max skip a NaN operand where a comparison with it is false: the two forms then differ only in cases whose distance is
+ * a NaN itself (a NaN numerator or denominator, 0 * infinity in a bound) -- a "hit" at a NaN distance, which neither scan can
+ * tell from a miss: getCollision's `distance < closest` and the shadow scan's `distance < dist` are false for it
+ * (src/RayTracer.cpp:75-78, 727-729), and take_nearer() / the running minimum skip it likewise. */
+__device__ __forceinline__ float plane_candidate_margin(const float numerator, const float denom, const float bound) {
+    const float same_sign = __builtin_fminf(numerator * __builtin_copysignf(1.0f, denom), fabsf(denom)) - 0x1p-149f;
+    const float prod = fabsf(denom) * bound;
+    /* !too_far: prod < 1e-30f (the float below it: 0x1.4484bep-100f) or |numerator| <= prod * 1.000001f */
+    const float near_enough = __builtin_fmaxf(0x1.4484bep-100f - prod, prod * 1.000001f - fabsf(numerator));
+    return __builtin_fminf(same_sign, near_enough);
+}
+
+/* SceneInfinitePlane::collision reduced to t, src/SceneInfinitePlane.cpp:29-51 */
+__device__ __forceinline__ float infinite_plane_hit_distance(const float4 q0, const V3 o, const V3 d, const float bound) {
+    const V3 n = xyz(q0);
+    const float numerator = -q0.w - dot3(o, n);
+    const float denom = dot3(d, n);
+    const float candidate = plane_candidate_margin(numerator, denom, bound);
+    float result = __builtin_huge_valf();
+    if (wave_any(candidate >= 0.0f)) {
+        const float t = numerator / denom;
+        /* hit <=> candidate && !(t < 1E-10) */
+        result = (__builtin_fminf(candidate, t - (float)1E-10) >= 0.0f) ? t : result;
+    }
+    return result;
+}
+
+/* SceneFinitePlane::collision for an axis-aligned rectangle, as aa_rectangle_distance() */
+__device__ __forceinline__ float aa_rectangle_hit_distance(const float4 r0, const float4 r1, const V3 op, const V3 dp, const float bound) {
+    const float numerator = -r0.x - op.x * r0.y;
+    const float denom = dp.x * r0.y;
+    const float candidate = plane_candidate_margin(numerator, denom, bound);
+    float result = __builtin_huge_valf();
+    if (wave_any(candidate >= 0.0f)) {
+        const float t = numerator / denom;
+        const float pa = dp.y * t + op.y;
+        const float pb = dp.z * t + op.z;
+        const float x = (pa - r1.x) * r0.z;
+        const float y = (pb - r1.y) * r0.w;
+        /* miss <=> (t <= 9.99999974737875e-06f) || (x < 0) || (x > r1.z) || (y < 0) || (y > r1.w); the float above that bound: 0x1.4f8b5ap-17f */
+        const float inside = __builtin_fminf(__builtin_fminf(__builtin_fminf(x, r1.z - x), __builtin_fminf(y, r1.w - y)), t - 0x1.4f8b5ap-17f);
+        result = (__builtin_fminf(candidate, inside) >= 0.0f) ? t : result;
+    }
+    return result;
+}
+
+/* SceneFinitePlane::collision reduced to t, src/SceneFinitePlane.cpp:86-124, as finite_plane_distance() */
+__device__ __forceinline__ float finite_plane_hit_distance(const float4 *g, const V3 o, const V3 d, const float bound) {
+    const float4 q0 = g[0];
+    const V3 n = xyz(q0);
+    const float numerator = -q0.w - dot3(o, n);
+    const float denom = dot3(d, n);
+    const float candidate = plane_candidate_margin(numerator, denom, bound);
+    float result = __builtin_huge_valf();
+    if (wave_any(candidate >= 0.0f)) {
+        const float4 q1 = g[1], q2 = g[2], q3 = g[3];
+        const float t = numerator / denom;
+        const V3 p = add3(scale3(d, t), o);
+        const V3 PO = sub3(p, xyz(q1));
+        const float x = dot3(PO, xyz(q2));
+        const float y = dot3(PO, xyz(q3));
+        const float inside = __builtin_fminf(__builtin_fminf(__builtin_fminf(x, q1.w - x), __builtin_fminf(y, q2.w - y)), t - 0x1.4f8b5ap-17f);
+        result = (__builtin_fminf(candidate, inside) >= 0.0f) ? t : result;
+    }
+    return result;
+}
+
 /* relative growth of a box that must contain every sphere the reference's float
  * arithmetic can report from a given origin; derived at box_needed() */
 #ifndef RT_SPHERE_SLACK
@@ -520,7 +562,7 @@ __device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
 /* Conservative box test for clustered sphere runs (rt_tables.h).  The box
  * [lo, hi] (already inflated on the host by 1 % of its largest extent + 1e-4)
  * contains every member sphere.  A member can only be a CANDIDATE of
- * sphere_distance() -- computed v >= 0 and computed d^2 >= 1e-9 -- if, with
+ * sphere_hit_distance() -- computed v >= 0 and computed d^2 >= 1e-9 -- if, with
  * D = |c_i - o|:
  *   the ray LINE passes within  r_eff = sqrt(r_i^2 + 1.4e-6 D^2) <= r_i + 1.2e-3 D
  *   of c_i  (the float evaluation of r^2 - (OE.OE - v*v) is off by at most
@@ -553,10 +595,13 @@ __device__ __forceinline__ bool box_needed(const float4 b0, const float4 b1, con
     const float az = (z0 - ex) * inv.z, bz = (z1 + ex) * inv.z;
     const float t_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float t_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    const bool miss = t_exit < t_enter - 1.0e-5f * (fabsf(t_enter) + fabsf(t_exit));
-    const bool behind = t_exit < -(1.0e-5f * fabsf(t_exit) + 1.0e-6f);
-    const bool beyond = t_enter - 1.0e-5f * fabsf(t_enter) > max_dist + 1.0e-3f * fabsf(max_dist) + 1.0e-6f;
-    return !(miss || behind || beyond);
+    /* no intersection (t_exit < t_enter), exit behind the origin (t_exit < 0) or entry beyond max_dist, each with the slab
+     * arithmetic's tolerance -- as ONE margin: the three conditions share the tolerance, so it is added to their minimum (a
+     * v_min3), and a NaN anywhere leaves the margin a NaN or positive: "needed" */
+    const float tolerance = __builtin_fmaf(1.0e-5f, fabsf(t_enter) + fabsf(t_exit), 1.0e-6f);
+    const float reach = __builtin_fmaf(1.0e-3f, fabsf(max_dist), max_dist);
+    const float margin = fminf(fminf(t_exit - t_enter, t_exit), reach - t_enter) + tolerance;
+    return !(margin < 0.0f);
 }
 
 /* A wave-uniform value, made opaque at the point of use: whatever is derived
@@ -1396,32 +1441,31 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
  * dependent ones, and no vector instruction spent on dispatch.  The culls are the ones of nearest_hit_items()
  * and in_shade(); the tests are the same routines on the same operands. */
 
-/* one candidate's exact distance test, dispatched on the (scalar) kind */
+/* one candidate's exact distance test, dispatched on the (scalar) kind: the distance the reference reports, +infinity for a miss */
 template <bool kStats>
-__device__ __forceinline__ void fast_item_distance(const RtParams &p, const float4 *lds, const uint32_t ctl,
-                                                   const float4 r0, const float4 r1, const V3 o, const V3 d,
-                                                   const float bound, const bool finite_rays, const bool counts,
-                                                   bool *hit, float *t, Stats<kStats> &st) {
+__device__ __forceinline__ float fast_item_distance(const RtParams &p, const float4 *lds, const uint32_t ctl,
+                                                    const float4 r0, const float4 r1, const V3 o, const V3 d,
+                                                    const float bound, const bool finite_rays, const bool counts, Stats<kStats> &st) {
     const int kind = (int)(ctl & 15u);
     if (kind >= RT_KIND_FINITE_AA && finite_rays) {
         st_wave(st, ST_WAVE_PLANE_TESTS);
         /* one copy of the test per axis of the normal: the rotation of the ray costs nothing then */
-        if (kind == RT_KIND_FINITE_AA)          aa_rectangle_distance(r0, r1, mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), bound, hit, t);
-        else if (kind == RT_KIND_FINITE_AA + 1) aa_rectangle_distance(r0, r1, mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), bound, hit, t);
-        else                                    aa_rectangle_distance(r0, r1, mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), bound, hit, t);
+        if (kind == RT_KIND_FINITE_AA)          return aa_rectangle_hit_distance(r0, r1, mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), bound);
+        else if (kind == RT_KIND_FINITE_AA + 1) return aa_rectangle_hit_distance(r0, r1, mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), bound);
+        else                                    return aa_rectangle_hit_distance(r0, r1, mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), bound);
     } else if (kind == RT_KIND_SPHERE) {
         st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, counts);
-        sphere_distance(r0, o, d, hit, t);
+        return sphere_hit_distance(r0, o, d);
     } else if (kind == RT_KIND_INFINITE_PLANE) {
         st_wave(st, ST_WAVE_PLANE_TESTS);
-        infinite_plane_distance(r0, o, d, bound, hit, t);
+        return infinite_plane_hit_distance(r0, o, d, bound);
     } else {
         /* a finite plane that is not axis-aligned -- or is, but some ray has a non-finite component: the general
          * routine on the full record (an AA item finds it through its Scene index) */
         st_wave(st, ST_WAVE_PLANE_TESTS);
         const uint32_t *lds_u32 = reinterpret_cast<const uint32_t *>(lds);
         const uint32_t full = kind == RT_KIND_FINITE_PLANE ? __float_as_uint(r1.x) : (lds_u32[p.objinfo_off * 4 + (ctl >> 8)] & 0xFFFFu);
-        finite_plane_distance(lds + full, o, d, bound, hit, t);
+        return finite_plane_hit_distance(lds + full, o, d, bound);
     }
 }
 
@@ -1499,10 +1543,8 @@ __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4
             const int item = base + src;
             const uint32_t ctl = ctl_words[item];
             const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
-            bool hit; float t;
-            fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, best, finite_rays, active, &hit, &t, st);
-            const int idx = (int)(ctl >> 8);
-            if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
+            const float t = fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, best, finite_rays, active, st);
+            take_nearer(t, (int)(ctl >> 8), &best, &best_idx);
         }
     }
     *best_out = best;
@@ -1560,9 +1602,8 @@ __device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *l
             mask &= mask - 1ull;
             const uint32_t ctl = ctl_words[item];
             const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
-            bool hit; float t;
-            fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, dist_to_light, finite_rays, !(nearest_block < dist_to_light), &hit, &t, st);
-            nearest_block = fminf(nearest_block, hit ? t : inf);
+            nearest_block = __builtin_fminf(nearest_block, fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, dist_to_light, finite_rays,
+                                                                                         !(nearest_block < dist_to_light), st));
         }
     }
     return nearest_block < dist_to_light;
@@ -1967,18 +2008,21 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
  * kernels -- asking the eight heads at once: 900 atomics per word at 88 per microsecond, 10-12 us until the median wavefront
  * had a tile (a built-in strip chunk is 100 us of work).  Every workgroup of the grid runs, so every one of these entries is
  * rendered exactly once whatever XCD the workgroup landed on (the queue is b mod 8, not the XCC_ID: placement is speed only). */
-__device__ __forceinline__ int first_entries(const int queue) {
-    const int blocks = (int)gridDim.x;
+/* (The first `heavy_blocks` workgroups of a launch with HEAVY tiles start with one of those and take their ordinary tiles from
+ * the queues afterwards: the entries handed out by arithmetic are the first of the order -- the most expensive rows -- and must
+ * not wait a quarter of a millisecond behind a HEAVY tile.  The others count from 0 behind them.) */
+__device__ __forceinline__ int first_entries(const int queue, const int heavy_blocks) {
+    const int blocks = (int)gridDim.x - heavy_blocks;
     return queue < blocks ? ((blocks - queue + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * (int)(blockDim.x >> 6) : 0;
 }
 
-__device__ RT_SCAN_INLINE unsigned int queues_with_tiles(const unsigned int *tile_counter, const int n_macros) {
+__device__ RT_SCAN_INLINE unsigned int queues_with_tiles(const unsigned int *tile_counter, const int n_macros, const int heavy_blocks) {
     const int lane = (int)(threadIdx.x & 63u);
     int left = 0;
     if (lane < RT_TILE_QUEUES) {
         const int len_k = lane < n_macros ? ((n_macros - lane + RT_TILE_QUEUES - 1) / RT_TILE_QUEUES) * RT_MACRO_ROWS : 0;
         const unsigned int taken = __hip_atomic_load(tile_counter + lane * RT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        left = len_k - first_entries(lane) - (int)min(taken, 0x3fffffffu);
+        left = len_k - first_entries(lane, heavy_blocks) - (int)min(taken, 0x3fffffffu);
     }
     return (unsigned int)__builtin_amdgcn_ballot_w64(left > 0) & 0xFFu;
 }
@@ -2064,8 +2108,10 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
      * scan from the first one on -- the HELP protocol with helpers that are there from the start.  The ordinary
      * tile queues skip the band.  (One loop hands out both kinds of tile, so that render_tile() is inlined once.) */
     int heavy_phase = 0;               /* 0: ordinary tiles; 1: this workgroup's first HEAVY tile (number blockIdx.x, no atomic); 2: further ones */
+    int heavy_blocks = 0;              /* the launch's first workgroups, which start with a HEAVY tile each (first_entries()) */
     if constexpr (kHelp) {
-        if (p.help_rays_quads != 0 && p.heavy_half >= 0) {
+        if (p.help_rays_quads != 0 && p.heavy_half >= 0) heavy_blocks = min((int)gridDim.x, (2 * p.heavy_half + 1) * p.tiles_x);
+        if ((int)blockIdx.x < heavy_blocks) {
             uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
             if ((threadIdx.x >> 6) == 0u) {
                 heavy_phase = 1;
@@ -2089,11 +2135,13 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     /* FIRST TILES WITHOUT THE QUEUES (above first_entries()): the wavefront starts on queue b mod 8 -- its own XCD's when
      * workgroups are dealt to the XCDs in turn, which nothing here relies on -- as if it had just been handed the entry
      * (b / 8) * wavefronts + w; from there on the loop is the one it always was */
-    const int home = (int)((blockIdx.x - (unsigned int)my_xcc) & (RT_TILE_QUEUES - 1));     /* queue b mod 8, counted from this XCD's */
+    const unsigned int ordinary_block = blockIdx.x - (unsigned int)heavy_blocks;             /* (wraps for the HEAVY workgroups, which ask the queues) */
+    const int home = (int)((ordinary_block - (unsigned int)my_xcc) & (RT_TILE_QUEUES - 1));     /* queue b mod 8, counted from this XCD's */
     int steal = home;
-    int next_pop = (int)(blockIdx.x >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) - first_entries((int)(blockIdx.x & (RT_TILE_QUEUES - 1)));
+    int next_pop = (int)(ordinary_block >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) -
+                   first_entries((int)(ordinary_block & (RT_TILE_QUEUES - 1)), heavy_blocks);
     unsigned int candidates = ~0u;     /* the other queues that had tiles when this wavefront's own ran dry (~0: not looked yet) */
-    bool fresh = false;                /* the current queue has not been asked yet */
+    bool fresh = (int)blockIdx.x < heavy_blocks;       /* the current queue has not been asked yet */
     for (;;) {
         int wave;                      /* tile number, row-major */
         if (kHelp && heavy_phase != 0) {
@@ -2101,7 +2149,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             int h = (int)blockIdx.x;
             if (heavy_phase == 2) {
                 if (lane == 0) h = (int)atomicAdd(heavy_head, 1u);
-                h = __builtin_amdgcn_readfirstlane(h) + (int)gridDim.x;
+                h = __builtin_amdgcn_readfirstlane(h) + heavy_blocks;
             }
             heavy_phase = 2;
             if (h >= (2 * p.heavy_half + 1) * p.tiles_x) {              /* the band is done: on to the ordinary tiles */
@@ -2121,7 +2169,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
             wave = tile_row * p.tiles_x + tile_col;
         } else {
             /* (a full circle from the queue it started on) */
-            if (steal >= RT_TILE_QUEUES + (int)((blockIdx.x - (unsigned int)my_xcc) & (RT_TILE_QUEUES - 1))) break;
+            if (steal >= RT_TILE_QUEUES + home) break;
             const int queue = (my_xcc + steal) & (RT_TILE_QUEUES - 1);
             unsigned int *const head = tile_counter + queue * RT_QUEUE_STRIDE;
             /* macro tiles queue, queue + 8, queue + 16, ... */
@@ -2131,7 +2179,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                 fresh = false;
             }
             /* a head counts the entries handed out beyond the wavefronts' first ones */
-            const int pop = __builtin_amdgcn_readfirstlane(next_pop) + first_entries(queue);
+            const int pop = __builtin_amdgcn_readfirstlane(next_pop) + first_entries(queue, heavy_blocks);
             if (pop >= queue_len) {
                 /* This queue is through.  Which of the others still have tiles is found by ONE look at all the heads, when this
                  * wavefront's own queue runs dry: an atomic on each exhausted queue in turn cost 3-4 us per queue -- 25 us
@@ -2144,7 +2192,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
                     ++steal;
                 } else {
                     if (candidates == ~0u) {
-                        const unsigned int nonempty = queues_with_tiles(tile_counter, n_macros);                   /* bit q: queue q */
+                        const unsigned int nonempty = queues_with_tiles(tile_counter, n_macros, heavy_blocks);                   /* bit q: queue q */
                         candidates = ((nonempty >> my_xcc) | (nonempty << (RT_TILE_QUEUES - my_xcc))) & 0xFFu & ~(1u << (steal & 7));     /* bit k: queue my_xcc + k; not the one just found empty */
                     }
                     if (candidates == 0u) break;
