@@ -104,25 +104,44 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
+# What a CU of gfx950 issues per cycle (scripts/ubench/issue_rate.hip, profiles/r04_issue_rate_ubench.txt, at the nominal 2.4 GHz):
+# 1.75 wave64 vector instructions (four SIMDs), and ONE scalar-unit instruction (0.97 measured: the scalar unit is shared by the
+# CU's four SIMDs; branches go through it too).  A 2 : 1 mix of vector and scalar instructions tops out at 1.56 + 0.78.
+VECTOR_PER_CU_CYCLE = 1.75
+SCALAR_PER_CU_CYCLE = 0.97
+N_CUS = N_SIMDS // 4
+
+
 def valu_issue_roofline(rec, kernel_ms):
-    """The binding roofline of this kernel: vector-instruction issue.  A wave64 fp32 instruction
-    occupies its SIMD-32 for 2 cycles by the guide (2.5 measured for dependent non-fused ops,
-    scripts/ubench/valu_rate.hip), so SQ_INSTS_VALU / 1 024 SIMDs x that = the cycles the VALU
-    pipes were busy; against the kernel's cycles (duration x 2.4 GHz)."""
+    """The binding roofline of these kernels: instruction issue.  SQ_INSTS_VALU and SQ_INSTS_SALU (+ SQ_INSTS_BRANCH where the
+    profile has it) per launch, per CU and cycle of the kernel (duration x 2.4 GHz), against what a CU was measured to issue.
+    `frac` is the vector figure; the scalar unit's is beside it -- the two limits are reached together by a 2 : 1 mix at 0.89 and
+    0.80 of them.  (The fractions of rounds 2-3 -- one vector instruction per 2 / 2.5 cycles and SIMD -- are kept for comparison.)"""
     insts = float(rec["sq_insts_valu"])
+    scalar = float(rec.get("sq_insts_salu") or 0.0) + float(rec.get("sq_insts_branch") or 0.0)
     kernel_cycles = kernel_ms * 1e-3 * CLOCK_HZ
     at2 = insts / N_SIMDS * 2.0
     at25 = insts / N_SIMDS * 2.5
+    per_cu = (lambda n: n / N_CUS / kernel_cycles) if kernel_cycles > 0 else (lambda n: None)
+    vec, sca = per_cu(insts), per_cu(scalar)
     return {
-        "bound": "valu_issue",
+        "bound": "instruction_issue",
         "sq_insts_valu_per_launch": insts,
         "sq_insts_salu_per_launch": rec.get("sq_insts_salu"),
+        "sq_insts_branch_per_launch": rec.get("sq_insts_branch"),
         "sq_busy_cycles_per_engine": rec.get("sq_busy_cycles_per_engine"),
         "kernel_cycles_at_2.4GHz": round(kernel_cycles, 0),
+        "vector_per_cu_and_cycle": round(vec, 3) if vec is not None else None,
+        "scalar_and_branch_per_cu_and_cycle": round(sca, 3) if sca is not None else None,
+        "peak_vector_per_cu_and_cycle": VECTOR_PER_CU_CYCLE,
+        "peak_scalar_per_cu_and_cycle": SCALAR_PER_CU_CYCLE,
+        "frac": round(vec / VECTOR_PER_CU_CYCLE, 4) if vec is not None else None,
+        "frac_scalar_unit": round(sca / SCALAR_PER_CU_CYCLE, 4) if sca is not None else None,
         "valu_issue_cycles_per_simd_at_2": round(at2, 0),
         "frac_at_2_cycles_per_wave64_op": round(at2 / kernel_cycles, 4) if kernel_cycles > 0 else None,
         "frac_at_2.5_cycles_measured": round(at25 / kernel_cycles, 4) if kernel_cycles > 0 else None,
-        "source": "SQ_INSTS_VALU from profiles/pmc_traffic.json (profiles/*_pmc_sq.csv), kernel time from this run's HIP events",
+        "source": "SQ_INSTS_* from profiles/pmc_traffic.json (profiles/*_pmc_sq.csv), kernel time from this run's HIP events; "
+                  "peaks from scripts/ubench/issue_rate.hip (profiles/r04_issue_rate_ubench.txt)",
     }
 
 

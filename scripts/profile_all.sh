@@ -5,8 +5,8 @@
 # configs a single GPU runs (built-in, grid-32, grid-16 depth 8), the 8192^2 frame, and the reference's SCENE 2
 # (two mirrors: the large-scene kernel).
 set -e
-D=${1:-r03}
-TAG=${2:-r03}
+D=${1:-r04}
+TAG=${2:-r04}
 R=$PWD
 O=$R/gpurun_out/$D
 mkdir -p $O
@@ -19,7 +19,7 @@ for w in $WL; do
   rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$w --output-format csv -- $B > $O/pmc_write_$w.log 2>&1
   rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$w --output-format csv -- $B > $O/pmc_fetch_$w.log 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY -d $O/sq1_$w --output-format csv -- $B > $O/sq1_$w.log 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d $O/sq2_$w --output-format csv -- $B > $O/sq2_$w.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH -d $O/sq2_$w --output-format csv -- $B > $O/sq2_$w.log 2>&1
   echo "$w counters done"
 done
 cd $R

@@ -77,6 +77,7 @@ for w in WORKLOADS:
         traffic[w]["sq_insts_valu"] = c["SQ_INSTS_VALU"]
         traffic[w]["sq_insts_salu"] = c.get("SQ_INSTS_SALU")
         traffic[w]["sq_insts_lds"] = c.get("SQ_INSTS_LDS")
+        traffic[w]["sq_insts_branch"] = c.get("SQ_INSTS_BRANCH")
         traffic[w]["sq_waves"] = c.get("SQ_WAVES")
         if c.get("SQ_BUSY_CYCLES"):
             traffic[w]["sq_busy_cycles_per_engine"] = c["SQ_BUSY_CYCLES"] / 32.0
