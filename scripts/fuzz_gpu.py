@@ -1,6 +1,6 @@
 """Randomised parity sweep, GPU kernel vs CPU oracle (development aid; the permanent cases live in tests/).
 
-usage: fuzz_gpu.py [first_seed=1000] [count=200] [only=0..3] [far=1] [option=value ...]
+usage: fuzz_gpu.py [first_seed=1000] [count=200] [only=0..3] [far=1] [bigfields=1] [option=value ...]
 far=1: every scene is a far-origin grazing scene (scene_gen.build_far_grazing) in a strip 8 columns wide and 4 096 ... 32 768 rows
 tall, whose rows around the middle hit the ground 1e4 ... 6e4 units away"""
 import os, sys, time
@@ -26,7 +26,7 @@ for seed in range(first, first + count):
         mk = lambda s: build_room(s, seed)
         W, H, depth = int(rng.randint(8, 120)), int(rng.randint(8, 120)), int(rng.randint(0, 7))
     elif seed % 4 == 0:
-        n = int(rng.choice([64, 80, 130, 260]))
+        n = int(rng.choice([300, 600, 1000] if kv.get("bigfields") == "1" else [64, 80, 130, 260]))   # bigfields=1: 15-50 leaves (the voxel table's automatic range)
         mk = lambda s: build_sphere_field(s, seed, n_spheres=n, spread=float(rng.choice([30.0, 60.0, 200.0])))
         W, H, depth = 40, int(rng.choice([64, 512, 2048])), int(rng.randint(1, 6))
     else:
@@ -40,7 +40,7 @@ for seed in range(first, first + count):
     orc = mk(oracle_lib.OracleScene())
     r = Renderer(host)
     for k, v in kv.items():                             # any other key=value: an rt_set_option for every scene (help=2 heavy=1 ...)
-        if k not in ("first_seed", "count", "only", "learn", "far"):
+        if k not in ("first_seed", "count", "only", "learn", "far", "bigfields"):
             r.set_option(k, int(v))
     if seed % 3 == 0:
         r.set_option("tile_z", int(2 ** rng.randint(0, 7)))

@@ -1147,6 +1147,36 @@ __device__ __forceinline__ void shading_point_bundle(const V3 lo, const V3 hi, V
     *centre = mk(uniform_f(c.x), uniform_f(c.y), uniform_f(c.z));
 }
 
+/* BOTH LIGHTS' SHADOW CULLS IN ONE PASS (FAST tables, two lights and at most 32 shadow items: the built-in scene).  A scan's bundle cull gives every item a lane; with 18-30 items half the wavefront idles, and the scan towards the
+ * other light repeats the pass.  Here lane i tests item i against the segments towards light 0 and lane 32 + i the same item
+ * against those towards light 1: the light's position is a per-lane select, and what the scans derive from it as wavefront-wide
+ * scalars (the centre segment, its reciprocals, the slack of its reach: in_shade()) is per-lane arithmetic done once for both
+ * -- the same test on the same numbers.  Bits 0-31 of the result: the candidates towards light 0, bits 32-63: towards light 1. */
+__device__ __forceinline__ unsigned long long shadow_cull_two_lights(const float4 *boxes, const int n_items, const V3 c, const V3 half,
+                                                                    const V3 light0, const V3 light1) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool second = lane >= 32;
+    const V3 light = mk(second ? light1.x : light0.x, second ? light1.y : light0.y, second ? light1.z : light0.z);
+    const V3 seg = sub3(light, c);
+    const V3 sinv = approx_inverse(seg);
+    const float reach = (fabsf(seg.x) + fabsf(seg.y) + fabsf(seg.z)) + (half.x + half.y + half.z);
+    const float grow_more = (RT_SPHERE_SLACK - RT_PLANE_SLACK) * reach;
+    const float grow = RT_PLANE_SLACK * reach + 1.0e-4f;
+    const int mine = min(lane & 31, n_items - 1);
+    const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
+    const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
+    const float gx = (half.x + grow) + more, gy = (half.y + grow) + more, gz = (half.z + grow) + more;
+    const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
+    const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
+    const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
+    const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    /* every comparison is false on a NaN, which then means "candidate" */
+    const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
+                       (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
+    return __builtin_amdgcn_ballot_w64((lane & 31) < n_items && !apart);
+}
+
 /* PAIRS (shadow scans of scenes with clustered sphere runs, kMode != 0).  The per-lane box
  * tests leave, for every candidate leaf, the lanes whose ray needs it; testing the leaf's
  * members for the whole wavefront then wastes the other lanes -- two thirds of them on the
@@ -1557,7 +1587,8 @@ __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4
 template <bool kStats>
 __device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *lds, const uint32_t *__restrict__ ctl_words,
                                               const bool active, const V3 o, const V3 d, const float dist_to_light,
-                                              const V3 light, const V3 origins_centre, const V3 origins_half, Stats<kStats> &st) {
+                                              const V3 light, const V3 origins_centre, const V3 origins_half,
+                                              const bool culled_already, const unsigned long long culled, Stats<kStats> &st) {
     const int n_items = p.n_fast_shadow;
     if (n_items == 0) return false;
     const float4 *boxes = lds + p.fast_box_off;
@@ -1566,6 +1597,26 @@ __device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *l
     st_wave(st, ST_WAVE_SHADOW);
     const float inf = __builtin_huge_valf();
     float nearest_block = active ? inf : -inf;
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool finite_rays = (__builtin_amdgcn_ballot_w64(!ray_is_finite(o, d)) & __builtin_amdgcn_ballot_w64(active)) == 0ull;
+    /* the candidates of one round of 64 items, in table order; true: every ray is blocked */
+    auto test_candidates = [&](unsigned long long mask, const int base) {
+        if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
+        while (mask != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(nearest_block < dist_to_light) == ~0ull) return true;
+            const int item = base + (__ffsll((long long)mask) - 1);
+            mask &= mask - 1ull;
+            const uint32_t ctl = ctl_words[item];
+            const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
+            nearest_block = __builtin_fminf(nearest_block, fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, dist_to_light, finite_rays,
+                                                                                         !(nearest_block < dist_to_light), st));
+        }
+        return false;
+    };
+    if (culled_already) {                    /* BOTH LIGHTS' SHADOW CULLS IN ONE PASS: at most 32 items */
+        if (test_candidates(culled, 0)) return true;
+        return nearest_block < dist_to_light;
+    }
     const V3 c = origins_centre;
     const V3 seg = sub3(light, c);
     V3 sinv = approx_inverse(seg);
@@ -1576,35 +1627,20 @@ __device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *l
     const float grow = RT_PLANE_SLACK * reach + 1.0e-4f;
     const V3 e = mk(uniform_f(origins_half.x + grow), uniform_f(origins_half.y + grow), uniform_f(origins_half.z + grow));
     sinv = mk(uniform_f(sinv.x), uniform_f(sinv.y), uniform_f(sinv.z));
-    const int lane = (int)(threadIdx.x & 63u);
-    const bool finite_rays = (__builtin_amdgcn_ballot_w64(!ray_is_finite(o, d)) & __builtin_amdgcn_ballot_w64(active)) == 0ull;
     for (int base = 0; base < n_items; base += 64) {
-        unsigned long long mask;
-        {
-            const int mine = min(base + lane, n_items - 1);
-            const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
-            const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
-            const float gx = e.x + more, gy = e.y + more, gz = e.z + more;
-            const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
-            const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
-            const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
-            const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-            const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-            /* every comparison is false on a NaN, which then means "candidate" */
-            const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
-                               (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
-            mask = __builtin_amdgcn_ballot_w64(base + lane < n_items && !apart);
-        }
-        if constexpr (kStats) { for (int k = __popcll(mask); k > 0; --k) st_wave(st, ST_SHADOW_CANDIDATES); }
-        while (mask != 0ull) {
-            if (__builtin_amdgcn_ballot_w64(nearest_block < dist_to_light) == ~0ull) return true;     /* every ray is blocked */
-            const int item = base + (__ffsll((long long)mask) - 1);
-            mask &= mask - 1ull;
-            const uint32_t ctl = ctl_words[item];
-            const float4 r0 = recs[2 * item], r1 = recs[2 * item + 1];
-            nearest_block = __builtin_fminf(nearest_block, fast_item_distance<kStats>(p, lds, ctl, r0, r1, o, d, dist_to_light, finite_rays,
-                                                                                         !(nearest_block < dist_to_light), st));
-        }
+        const int mine = min(base + lane, n_items - 1);
+        const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
+        const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
+        const float gx = e.x + more, gy = e.y + more, gz = e.z + more;
+        const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
+        const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
+        const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
+        const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        /* every comparison is false on a NaN, which then means "candidate" */
+        const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
+                           (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
+        if (test_candidates(__builtin_amdgcn_ballot_w64(base + lane < n_items && !apart), base)) return true;
     }
     return nearest_block < dist_to_light;
 }
@@ -1843,17 +1879,30 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
             if constexpr (kMode == 4 || kMode == 5) {
                 if (p.svox_off != 0) wave_or_u64x2(voxel_masks.x, voxel_masks.y, voxel_masks.z, voxel_masks.w, &voxels_say0, &voxels_say1);
             }
+            /* BOTH LIGHTS' SHADOW CULLS IN ONE PASS, where the table allows (above in_shade()) */
+            /* (the FAST scans only: the clustered-scene kernels paid for the extra code with 18 more spilled scalars -- 256-sphere
+             * grid, 18 items: 3.900 -> 3.892 ms with it, the 1 024-sphere grid, 45 items and no use for it, 3.668 -> 3.709) */
+            bool both_culls = false;
+            unsigned long long culled_both = 0ull;
+            if constexpr (kMode == 6) {
+                both_culls = p.n_lights == 2 && p.n_fast_shadow > 0 && p.n_fast_shadow <= 32;
+                if (both_culls)
+                    culled_both = shadow_cull_two_lights(lds + p.fast_box_off, p.n_fast_shadow, bundle_centre, bundle_half,
+                                                         xyz(lds[p.lights_off]), xyz(lds[p.lights_off + RT_LIGHT_QUADS]));
+            }
             for (int l = 0; l < p.n_lights; ++l) {
                 const float4 l0 = lds[p.lights_off + l * RT_LIGHT_QUADS];
                 const float4 l1 = lds[p.lights_off + l * RT_LIGHT_QUADS + 1];
                 const unsigned long long voxels_say = l == 0 ? voxels_say0 : (l == 1 ? voxels_say1 : ~0ull);
+                const unsigned long long culled = l == 0 ? (culled_both & 0xFFFFFFFFull) : (culled_both >> 32);
                 /* inShade, :743-771 */
                 const V3 dir = sub3(xyz(l0), P);
                 float dist_to_light;                         /* |dir|, :748 -- the length normalize3() takes the root of anyway */
                 const V3 light_ray = normalize3(dir, &dist_to_light);        /* == Ray(P, dir).direction == cosineShade's light_ray == specular L */
                 const unsigned long long t_shadow = st_clock<kStats>();
                 bool blocked;
-                if constexpr (kMode == 6) blocked = in_shade_fast<kStats>(p, lds, ctl_words, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half, st);
+                if constexpr (kMode == 6) blocked = in_shade_fast<kStats>(p, lds, ctl_words, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half,
+                                                                          both_culls, culled, st);
                 else blocked = in_shade<kStats, kMode>(p, lds, wlds, help_rays, shade, P, light_ray, dist_to_light, xyz(l0), bundle_centre, bundle_half,
                                                        voxels_say, st);
                 st_cycles(st, ST_CYCLES_SHADOW, t_shadow);
