@@ -354,6 +354,28 @@ __device__ __forceinline__ float sphere_blocks(const float4 s, const V3 o, const
     return blocked;
 }
 
+/* two, the same way (the pair flush of the 80-register kernel, which does not hold four) */
+__device__ __forceinline__ float two_spheres_block(const float4 s0, const float4 s1, const V3 o, const V3 d, const ShadowRay ray, float blocked) {
+    const V3 e0 = mk(s0.x - o.x, s0.y - o.y, s0.z - o.z), e1 = mk(s1.x - o.x, s1.y - o.y, s1.z - o.z);
+    const float v0 = dot3(e0, d), v1 = dot3(e1, d);
+    const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);
+    const float m0 = sphere_margin(v0, q0), m1 = sphere_margin(v1, q1);
+    const float candidate = __builtin_fmaxf(m0, m1);
+    if (wave_any(__builtin_fminf(candidate, -blocked) >= 0.0f)) {
+        const float u0 = __builtin_fminf(m0, __builtin_fminf(ray.limit - v0, 1.0e9f - q0));
+        const float u1 = __builtin_fminf(m1, __builtin_fminf(ray.limit - v1, 1.0e9f - q1));
+        const bool plain = sphere_operands_plain(fabsf(q0) + fabsf(q1));
+        blocked = plain ? __builtin_fmaxf(blocked, __builtin_fmaxf(u0, u1)) : blocked;
+        if (wave_any(!plain || __builtin_fminf(candidate, -blocked) >= 0.0f)) {
+            float t0, t1;
+            if (wave_any(!plain)) { t0 = sphere_hit_or_inf_exact(v0, q0); t1 = sphere_hit_or_inf_exact(v1, q1); }
+            else { t0 = sphere_hit_or_inf(v0, sqrt_in_range(q0), m0); t1 = sphere_hit_or_inf(v1, sqrt_in_range(q1), m1); }
+            blocked = (__builtin_fminf(t0, t1) < ray.dist) ? 1.0f : blocked;
+        }
+    }
+    return blocked;
+}
+
 template <bool kStats, bool kAbreast>
 __device__ __forceinline__ bool leaf_members_block(const float4 *g, const int n, const V3 o, const V3 d, const float dist_to_light,
                                                    const bool lane_needs, const bool blocked_in, Stats<kStats> &st) {
@@ -1207,6 +1229,9 @@ __device__ __forceinline__ unsigned long long shadow_cull_two_lights(const float
 #ifndef RT_NT_STORES
 #define RT_NT_STORES 1           /* the image leaves through streaming stores (HBM bytes per built-in frame 272 -> 241 MB) */
 #endif
+#ifndef RT_FLUSH_TWO_ABREAST
+#define RT_FLUSH_TWO_ABREAST 1     /* the 80-register kernel's pair flush tests two members abreast (four: 23 spilled registers, grid-32 3.68 -> 3.73 ms; two: 7, 3.68 -> 3.64; r04_experiments 14) */
+#endif
 #ifndef RT_LEAVES_ABREAST
 #define RT_LEAVES_ABREAST 1           /* shadow scans: the box tests of two consecutive candidate leaves side by side (grid-32 5.14 -> 4.99 ms) */
 #endif
@@ -1241,12 +1266,21 @@ __device__ __forceinline__ bool flush_shadow_pairs(const float4 *lds, ShadowPair
                                               lds[geom + (i + 2 < count ? j2 : 0)], lds[geom + (i + 3 < count ? j3 : 0)], po, pd, ray, pair_verdict);
         }
     } else {
+#if RT_FLUSH_TWO_ABREAST
+        for (int i = 0; wave_any(i < members); i += 2) {
+            int j0 = i + rot, j1 = i + 1 + rot;
+            j0 = j0 >= count ? j0 - count : j0; j1 = j1 >= count ? j1 - count : j1;
+            if constexpr (kStats) { for (int k = 0; k < 2; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i + k < members); } }
+            pair_verdict = two_spheres_block(lds[geom + (i < count ? j0 : 0)], lds[geom + (i + 1 < count ? j1 : 0)], po, pd, ray, pair_verdict);
+        }
+#else
         for (int i = 0; wave_any(i < members); ++i) {
             int j = i + rot;
             j = j >= count ? j - count : j;
             st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i < members);
             pair_verdict = sphere_blocks(lds[geom + (i < count ? j : 0)], po, pd, ray, pair_verdict);
         }
+#endif
     }
     const bool pair_blocked = has && pair_verdict >= 0.0f;
     /* the verdicts, back to the rays' lanes (few pairs block) */
@@ -1267,7 +1301,7 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                                          const unsigned long long voxels_say, Stats<kStats> &st) {
     constexpr bool kPairs = kMode != 0;
     constexpr bool kHelped = kMode == 4 || kMode == 5;      /* a first-pass tile of a clustered scene: HELP */
-    constexpr bool kRoomy = kMode == 5;                     /* the kernel with registers to spare: the pair flush tests four members abreast */
+    constexpr bool kRoomy = kMode == 5;                     /* the kernel with registers to spare: the pair flush tests four members abreast (the other: two) */
     ShadowPairs pairs = {0, 0};
     bool blocked = !active;
     int stat_my_leaves = 0;
@@ -2162,7 +2196,9 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
         if (p.help_rays_quads != 0 && p.heavy_half >= 0) heavy_blocks = min((int)gridDim.x, (2 * p.heavy_half + 1) * p.tiles_x);
         if ((int)blockIdx.x < heavy_blocks) {
             uint32_t *desk = reinterpret_cast<uint32_t *>(wlds + p.desk_off);
-            if ((threadIdx.x >> 6) == 0u) {
+            /* (the wavefront's number as a scalar: a condition on threadIdx.x counts as divergent, and with it everything the tile
+             * loop carries -- queue, pop, phase -- would live in vector registers, spilled across every tile) */
+            if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
                 heavy_phase = 1;
                 if (lane == 0) desk_write(desk, RT_DESK_DEDICATED, 1u);
             } else {
@@ -2187,7 +2223,7 @@ __device__ __forceinline__ void render_body(const RtParams &p, const float4 *__r
     const unsigned int ordinary_block = blockIdx.x - (unsigned int)heavy_blocks;             /* (wraps for the HEAVY workgroups, which ask the queues) */
     const int home = (int)((ordinary_block - (unsigned int)my_xcc) & (RT_TILE_QUEUES - 1));     /* queue b mod 8, counted from this XCD's */
     int steal = home;
-    int next_pop = (int)(ordinary_block >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) -
+    int next_pop = (int)(ordinary_block >> 3) * (int)(blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) -
                    first_entries((int)(ordinary_block & (RT_TILE_QUEUES - 1)), heavy_blocks);
     unsigned int candidates = ~0u;     /* the other queues that had tiles when this wavefront's own ran dry (~0: not looked yet) */
     bool fresh = (int)blockIdx.x < heavy_blocks;       /* the current queue has not been asked yet */
