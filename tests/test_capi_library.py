@@ -136,6 +136,19 @@ def test_no_gpu_means_no_render(have_gpu):
     assert rc == capi.RT_ERR_NO_DEVICE and not out.any()
 
 
+@pytest.mark.parametrize("name", ["grid32", "grid16", "grid9", "twomirrors"])
+def test_packing_a_clustered_scene_needs_no_gpu_and_then_says_so(have_gpu, name):
+    """rt_scene_create packs the tables -- sphere clusters, item tables, and for the 1 024-sphere grid the SHADOW VOXELS
+    (csrc/rt_capi.hip: shadow_voxels(), 4 096 voxels x 43 leaves x 2 lights) -- on the host before it asks for a device: on a
+    machine without a GPU the whole packer runs and the call then fails with RT_ERR_NO_DEVICE, not with a crash."""
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    from tilecoderaytracer_amd import Renderer
+    with pytest.raises(RtError) as e:
+        Renderer(HostScene.named(name))
+    assert e.value.code == capi.RT_ERR_NO_DEVICE
+
+
 def test_product_does_not_reference_the_oracle():
     """The oracle is test infrastructure: nothing under the package, include/
     or bench.py's product path may import, link or load it."""
