@@ -396,7 +396,19 @@ __device__ __forceinline__ bool leaf_members_block(const float4 *g, const int n,
     return blocked >= 0.0f;
 }
 
-/* Plane prefilter shared by both plane kinds.  t = numerator / denom is only
+/* PLANE TESTS WITHOUT SCALAR INSTRUCTIONS (see SPHERE TESTS WITHOUT SCALAR INSTRUCTIONS above for why).  Every accept / reject
+ * condition of the reference's plane routines is written as a MARGIN (>= 0: passes) and the conditions are combined by minima:
+ * one comparison and one select per test where the `&&` / `||` forms take a v_cmp per condition and an s_and / s_or per
+ * operator.  The result is the distance the reference reports, or +infinity for a miss.
+ *   x > 0   <=>  x - 0x1p-149f >= 0   (denormals are kept: the smallest one is representable)
+ *   x <= c  <=>  c - x >= 0, x < c <=> pred(c) - x >= 0: a float difference of floats has the sign of the exact one
+ *   numerator and denominator non-zero with equal signs  <=>  min(numerator * copysign(1, denom), |denom|) > 0
+ * min / max skip a NaN operand where a comparison with it is false: the two forms then differ only in cases whose distance is
+ * a NaN itself (a NaN numerator or denominator, 0 * infinity in a bound) -- a "hit" at a NaN distance, which neither scan can
+ * tell from a miss: getCollision's `distance < closest` and the shadow scan's `distance < dist` are false for it
+ * (src/RayTracer.cpp:75-78, 727-729), and take_nearer() / the running minimum skip it likewise. */
+
+/* Plane prefilter shared by both plane kinds (>= 0: the quotient is worth computing).  t = numerator / denom is only
  * worth computing when it can matter; both skips are exact:
  *  (1) unless numerator and denom are non-zero with equal signs, t <= 0 (or
  *      NaN, which loses every later comparison): the reference's `t < 1E-10` /
@@ -405,100 +417,6 @@ __device__ __forceinline__ bool leaf_members_block(const float4 *g, const int n,
  *      the product, and only when the product is a normal number), the true
  *      quotient exceeds `bound`, so the correctly rounded t is >= bound and the
  *      caller's `t < bound` (nearest so far / distance to the light) is false. */
-__device__ __forceinline__ bool plane_candidate(const float numerator, const float denom, const float bound) {
-    const bool same_sign = (numerator > 0.0f && denom > 0.0f) || (numerator < 0.0f && denom < 0.0f);
-    const float prod = fabsf(denom) * bound;
-    const bool too_far = (prod >= 1.0e-30f) && (fabsf(numerator) > prod * 1.000001f);
-    return same_sign && !too_far;
-}
-
-/* SceneInfinitePlane::collision reduced to t, src/SceneInfinitePlane.cpp:29-51 */
-__device__ __forceinline__ void infinite_plane_distance(const float4 q0, const V3 o, const V3 d, const float bound,
-                                                        bool *hit, float *dist) {
-    const V3 n = xyz(q0);
-    const float numerator = -q0.w - dot3(o, n);
-    const float denom = dot3(d, n);
-    const bool candidate = plane_candidate(numerator, denom, bound);
-    *hit = false;
-    *dist = 0.0f;
-    if (wave_any(candidate)) {
-        const float t = numerator / denom;
-        *hit = candidate && !(t < (float)1E-10);
-        *dist = t;
-    }
-}
-
-/* SceneFinitePlane::collision reduced to t, src/SceneFinitePlane.cpp:86-124 */
-__device__ __forceinline__ void finite_plane_distance(const float4 *g, const V3 o, const V3 d, const float bound,
-                                                      bool *hit, float *dist) {
-    const float4 q0 = g[0];
-    const V3 n = xyz(q0);
-    const float numerator = -q0.w - dot3(o, n);
-    const float denom = dot3(d, n);
-    const bool candidate = plane_candidate(numerator, denom, bound);
-    *hit = false;
-    *dist = 0.0f;
-    if (wave_any(candidate)) {
-        const float4 q1 = g[1], q2 = g[2], q3 = g[3];
-        const float t = numerator / denom;
-        const V3 p = add3(scale3(d, t), o);
-        const V3 PO = sub3(p, xyz(q1));
-        const float x = dot3(PO, xyz(q2));
-        const float y = dot3(PO, xyz(q3));
-        /* `t < 1E-5` is a double comparison in the reference (:102);
-         * (double)t < 1e-5  <=>  t <= 9.99999974737875e-06f, the float just below 1e-5 */
-        const bool miss = (t <= 9.99999974737875e-06f) || (x < 0) || (x > q1.w) || (y < 0) || (y > q2.w);
-        *hit = candidate && !miss;
-        *dist = t;
-    }
-}
-
-/* Axis-aligned rectangles (everything Scene::makeSceneBox builds,
- * src/Scene.cpp:392-416: normal, horizontal and vertical are +-unit axes).
- * With n = sn*e_n, h = sh*e_a, v = sv*e_b the reference's dot products reduce to
- * one multiplication by +-1 plus additions of +-0:
- *     o.n = (o_n*sn + (+-0)) + (+-0),   x = PO.h = ((+-0) + PO_a*sh) + (+-0), ...
- * For a ray whose origin and direction are all FINITE those zeros can only
- * change the sign of a zero result, and a zero numerator, denominator, x or y
- * takes the same branch whatever its sign (t = +-0 is rejected by `t < 1E-5`,
- * `denom == 0` and `x < 0` do not see the sign).  So, in coordinates permuted
- * to (n, a, b), SceneFinitePlane::collision (src/SceneFinitePlane.cpp:86-124)
- * is evaluated with a third of the arithmetic and an identical outcome.  Rays
- * with a non-finite component take the general routine instead (inf*0 = NaN
- * would differ).  Record: r0 = {dto, sn, sh, sv}, r1 = {po_a, po_b, h_dist, v_dist}
- * (h_dist, v_dist >= 0). */
-__device__ __forceinline__ void aa_rectangle_distance(const float4 r0, const float4 r1, const V3 op, const V3 dp,
-                                                      const float bound, bool *hit, float *dist) {
-    const float numerator = -r0.x - op.x * r0.y;
-    const float denom = dp.x * r0.y;
-    const bool candidate = plane_candidate(numerator, denom, bound);
-    *hit = false;
-    *dist = 0.0f;
-    if (wave_any(candidate)) {
-        const float t = numerator / denom;
-        const float pa = dp.y * t + op.y;
-        const float pb = dp.z * t + op.z;
-        const float x = (pa - r1.x) * r0.z;
-        const float y = (pb - r1.y) * r0.w;
-        const bool miss = (t <= 9.99999974737875e-06f) || (x < 0) || (x > r1.z) || (y < 0) || (y > r1.w);
-        *hit = candidate && !miss;
-        *dist = t;
-    }
-}
-
-
-/* PLANE TESTS WITHOUT SCALAR INSTRUCTIONS (the FAST scans; see SPHERE TESTS WITHOUT SCALAR INSTRUCTIONS above for why).  The
- * same tests as plane_candidate() / infinite_plane_distance() / aa_rectangle_distance() / finite_plane_distance(), with every
- * accept / reject condition written as a MARGIN (>= 0: passes) and the conditions combined by minima: one comparison and one
- * select per test where the `&&` / `||` forms take a v_cmp per condition and an s_and / s_or per operator.  The result is the
- * distance the reference reports, or +infinity for a miss.
- *   x > 0   <=>  x - 0x1p-149f >= 0   (denormals are kept: the smallest one is representable)
- *   x <= c  <=>  c - x >= 0, x < c <=> pred(c) - x >= 0: a float difference of floats has the sign of the exact one
- *   numerator and denominator non-zero with equal signs  <=>  min(numerator * copysign(1, denom), |denom|) > 0
- * min / max skip a NaN operand where a comparison with it is false: the two forms then differ only in cases whose distance is
- * a NaN itself (a NaN numerator or denominator, 0 * infinity in a bound) -- a "hit" at a NaN distance, which neither scan can
- * tell from a miss: getCollision's `distance < closest` and the shadow scan's `distance < dist` are false for it
- * (src/RayTracer.cpp:75-78, 727-729), and take_nearer() / the running minimum skip it likewise. */
 __device__ __forceinline__ float plane_candidate_margin(const float numerator, const float denom, const float bound) {
     const float same_sign = __builtin_fminf(numerator * __builtin_copysignf(1.0f, denom), fabsf(denom)) - 0x1p-149f;
     const float prod = fabsf(denom) * bound;
@@ -522,26 +440,7 @@ __device__ __forceinline__ float infinite_plane_hit_distance(const float4 q0, co
     return result;
 }
 
-/* SceneFinitePlane::collision for an axis-aligned rectangle, as aa_rectangle_distance() */
-__device__ __forceinline__ float aa_rectangle_hit_distance(const float4 r0, const float4 r1, const V3 op, const V3 dp, const float bound) {
-    const float numerator = -r0.x - op.x * r0.y;
-    const float denom = dp.x * r0.y;
-    const float candidate = plane_candidate_margin(numerator, denom, bound);
-    float result = __builtin_huge_valf();
-    if (wave_any(candidate >= 0.0f)) {
-        const float t = numerator / denom;
-        const float pa = dp.y * t + op.y;
-        const float pb = dp.z * t + op.z;
-        const float x = (pa - r1.x) * r0.z;
-        const float y = (pb - r1.y) * r0.w;
-        /* miss <=> (t <= 9.99999974737875e-06f) || (x < 0) || (x > r1.z) || (y < 0) || (y > r1.w); the float above that bound: 0x1.4f8b5ap-17f */
-        const float inside = __builtin_fminf(__builtin_fminf(__builtin_fminf(x, r1.z - x), __builtin_fminf(y, r1.w - y)), t - 0x1.4f8b5ap-17f);
-        result = (__builtin_fminf(candidate, inside) >= 0.0f) ? t : result;
-    }
-    return result;
-}
-
-/* SceneFinitePlane::collision reduced to t, src/SceneFinitePlane.cpp:86-124, as finite_plane_distance() */
+/* SceneFinitePlane::collision reduced to t, src/SceneFinitePlane.cpp:86-124 */
 __device__ __forceinline__ float finite_plane_hit_distance(const float4 *g, const V3 o, const V3 d, const float bound) {
     const float4 q0 = g[0];
     const V3 n = xyz(q0);
@@ -556,7 +455,40 @@ __device__ __forceinline__ float finite_plane_hit_distance(const float4 *g, cons
         const V3 PO = sub3(p, xyz(q1));
         const float x = dot3(PO, xyz(q2));
         const float y = dot3(PO, xyz(q3));
+        /* `t < 1E-5` is a double comparison in the reference (:102): (double)t < 1e-5 <=> t <= 9.99999974737875e-06f, the float just
+         * below 1e-5; the float above that one: 0x1.4f8b5ap-17f.  miss <=> t <= ... || x < 0 || x > h_dist || y < 0 || y > v_dist */
         const float inside = __builtin_fminf(__builtin_fminf(__builtin_fminf(x, q1.w - x), __builtin_fminf(y, q2.w - y)), t - 0x1.4f8b5ap-17f);
+        result = (__builtin_fminf(candidate, inside) >= 0.0f) ? t : result;
+    }
+    return result;
+}
+
+/* Axis-aligned rectangles (everything Scene::makeSceneBox builds,
+ * src/Scene.cpp:392-416: normal, horizontal and vertical are +-unit axes).
+ * With n = sn*e_n, h = sh*e_a, v = sv*e_b the reference's dot products reduce to
+ * one multiplication by +-1 plus additions of +-0:
+ *     o.n = (o_n*sn + (+-0)) + (+-0),   x = PO.h = ((+-0) + PO_a*sh) + (+-0), ...
+ * For a ray whose origin and direction are all FINITE those zeros can only
+ * change the sign of a zero result, and a zero numerator, denominator, x or y
+ * takes the same branch whatever its sign (t = +-0 is rejected by `t < 1E-5`,
+ * `denom == 0` and `x < 0` do not see the sign).  So, in coordinates permuted
+ * to (n, a, b), SceneFinitePlane::collision (src/SceneFinitePlane.cpp:86-124)
+ * is evaluated with a third of the arithmetic and an identical outcome.  Rays
+ * with a non-finite component take the general routine instead (inf*0 = NaN
+ * would differ).  Record: r0 = {dto, sn, sh, sv}, r1 = {po_a, po_b, h_dist, v_dist}
+ * (h_dist, v_dist >= 0). */
+__device__ __forceinline__ float aa_rectangle_hit_distance(const float4 r0, const float4 r1, const V3 op, const V3 dp, const float bound) {
+    const float numerator = -r0.x - op.x * r0.y;
+    const float denom = dp.x * r0.y;
+    const float candidate = plane_candidate_margin(numerator, denom, bound);
+    float result = __builtin_huge_valf();
+    if (wave_any(candidate >= 0.0f)) {
+        const float t = numerator / denom;
+        const float pa = dp.y * t + op.y;
+        const float pb = dp.z * t + op.z;
+        const float x = (pa - r1.x) * r0.z;
+        const float y = (pb - r1.y) * r0.w;
+        const float inside = __builtin_fminf(__builtin_fminf(__builtin_fminf(x, r1.z - x), __builtin_fminf(y, r1.w - y)), t - 0x1.4f8b5ap-17f);
         result = (__builtin_fminf(candidate, inside) >= 0.0f) ? t : result;
     }
     return result;
@@ -756,8 +688,9 @@ __device__ __forceinline__ bool nearer(const float t, const int idx, const float
     return t < best || (t == best && idx < best_idx);
 }
 /* (best, best_idx) := the earlier of it and (t, idx) in that order, without a branch or a scalar instruction (SPHERE TESTS
- * WITHOUT SCALAR INSTRUCTIONS, above): t is a reported distance or +infinity, never a NaN; best_idx = -1 (nothing yet) goes
- * with best = 65535, which no reported distance reaches */
+ * WITHOUT SCALAR INSTRUCTIONS, above): t is a reported distance or +infinity -- or, from a plane test, a NaN, which loses both
+ * comparisons and is skipped by the minimum: nothing changes, as in the reference's `distance < closest` --; best_idx = -1
+ * (nothing yet) goes with best = 65535, which no reported distance reaches */
 __device__ __forceinline__ void take_nearer(const float t, const int idx, float *best, int *best_idx) {
     const int on_tie = min(idx, *best_idx);
     const int kept = (t == *best) ? on_tie : *best_idx;
@@ -1085,7 +1018,7 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
             const int kind = (int)(bits & 15u);
             const float4 *g = lds + (bits >> 16);
             const int idx = (int)(bits1 & 4095u);
-            bool hit; float t;
+            float t;
             if (kind == RT_KIND_SPHERE) {
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, active);
                 take_nearer(sphere_hit_distance(g[0], o, d), idx, &best, &best_idx);
@@ -1121,20 +1054,18 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                 }
             } else if (kind == RT_KIND_INFINITE_PLANE) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                infinite_plane_distance(g[0], o, d, best, &hit, &t);
-                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
+                take_nearer(infinite_plane_hit_distance(g[0], o, d, best), idx, &best, &best_idx);
             } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 3 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 const int axis = kind - RT_KIND_FINITE_AA;             /* of the normal; the record is in cyclic order from it */
                 /* one copy of the test per axis: the rotation costs nothing then (six moves otherwise) */
-                if (axis == 0)      aa_rectangle_distance(g[0], g[1], mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), best, &hit, &t);
-                else if (axis == 1) aa_rectangle_distance(g[0], g[1], mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), best, &hit, &t);
-                else                aa_rectangle_distance(g[0], g[1], mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), best, &hit, &t);
-                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
+                if (axis == 0)      t = aa_rectangle_hit_distance(g[0], g[1], mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), best);
+                else if (axis == 1) t = aa_rectangle_hit_distance(g[0], g[1], mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), best);
+                else                t = aa_rectangle_hit_distance(g[0], g[1], mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), best);
+                take_nearer(t, idx, &best, &best_idx);
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                finite_plane_distance(lds + (bits1 >> 12), o, d, best, &hit, &t);
-                if (hit && nearer(t, idx, best, best_idx)) { best = t; best_idx = idx; }
+                take_nearer(finite_plane_hit_distance(lds + (bits1 >> 12), o, d, best), idx, &best, &best_idx);
             }
         }
     }
@@ -1428,7 +1359,6 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             const uint32_t bits = __float_as_uint(i0.w), bits1 = __float_as_uint(i1.w);
             const int kind = (int)(bits & 15u);
             const float4 *g = lds + (bits >> 16);
-            bool hit; float t;
             if (kind == RT_KIND_SPHERE) {
                 st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, !blocked);
                 blocked = sphere_blocks(g[0], o, d, shadow_ray(dist_to_light), blocked_number(blocked)) >= 0.0f;
@@ -1476,20 +1406,19 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
                 take_leaf(bits, lane_needs, needers);
             } else if (kind == RT_KIND_INFINITE_PLANE) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                infinite_plane_distance(g[0], o, d, dist_to_light, &hit, &t);
-                blocked = blocked || (hit && t < dist_to_light);
+                blocked = blocked || infinite_plane_hit_distance(g[0], o, d, dist_to_light) < dist_to_light;
             } else if (kind >= RT_KIND_FINITE_AA && kind < RT_KIND_FINITE_AA + 3 && finite_rays) {
                 st_wave(st, ST_WAVE_PLANE_TESTS);
                 const int axis = kind - RT_KIND_FINITE_AA;
                 /* one copy of the test per axis: the rotation costs nothing then (six moves otherwise) */
-                if (axis == 0)      aa_rectangle_distance(g[0], g[1], mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), dist_to_light, &hit, &t);
-                else if (axis == 1) aa_rectangle_distance(g[0], g[1], mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), dist_to_light, &hit, &t);
-                else                aa_rectangle_distance(g[0], g[1], mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), dist_to_light, &hit, &t);
-                blocked = blocked || (hit && t < dist_to_light);
+                float t;
+                if (axis == 0)      t = aa_rectangle_hit_distance(g[0], g[1], mk(o.x, o.y, o.z), mk(d.x, d.y, d.z), dist_to_light);
+                else if (axis == 1) t = aa_rectangle_hit_distance(g[0], g[1], mk(o.y, o.z, o.x), mk(d.y, d.z, d.x), dist_to_light);
+                else                t = aa_rectangle_hit_distance(g[0], g[1], mk(o.z, o.x, o.y), mk(d.z, d.x, d.y), dist_to_light);
+                blocked = blocked || t < dist_to_light;
             } else {                                             /* finite plane, general routine on the full record */
                 st_wave(st, ST_WAVE_PLANE_TESTS);
-                finite_plane_distance(lds + (bits1 >> 12), o, d, dist_to_light, &hit, &t);
-                blocked = blocked || (hit && t < dist_to_light);
+                blocked = blocked || finite_plane_hit_distance(lds + (bits1 >> 12), o, d, dist_to_light) < dist_to_light;
             }
         }
     }
@@ -1883,9 +1812,7 @@ __device__ __forceinline__ void render_tile(const RtParams &p, const float4 *lds
                         cx = svox_axis_cell(ux, p.svox_n[0]); cy = svox_axis_cell(uy, p.svox_n[1]); cz = svox_axis_cell(uz, p.svox_n[2]);
                         in_grid = (cx | cy | cz) >= 0;
                     }
-#ifndef RT_SVOX_UNSAFE_OUTSIDE                               /* (EXPERIMENT ONLY when defined: lanes outside the grid ask for nothing -- wrong pixels) */
-                    if (shade) voxel_masks = make_uint4(~0u, ~0u, ~0u, ~0u);
-#endif
+                    if (shade) voxel_masks = make_uint4(~0u, ~0u, ~0u, ~0u);     /* (outside the grid: any item may matter) */
                     if (shade && in_grid) {
                         const int voxel = (cz * (p.svox_n[1] + 2 * RT_SVOX_TAIL) + cy) * (p.svox_n[0] + 2 * RT_SVOX_TAIL) + cx;
                         voxel_masks = (reinterpret_cast<const uint4 *>(ctl_words) + (size_t)p.svox_off)[voxel];
