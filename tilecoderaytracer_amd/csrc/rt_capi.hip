@@ -188,6 +188,20 @@ void split_leaves(const rt_object_desc *objs, std::vector<int> ids, int leaf, st
  * depth 50: 0.692 -> 0.626 ms there, but 0.445 -> 0.649 ms with its tables forced into LDS). */
 int auto_leaf(int n, bool tables_in_lds) { return n < 512 ? 16 : (n < 896 ? 20 : ((n < 3000 || tables_in_lds) ? 24 : 32)); }
 
+/* An item's box as the kernel reads it (rt_tables.h): CENTRE and HALF-EXTENT per axis, such that [c - h, c + h] in real
+ * arithmetic contains [lo, hi]; an axis the item is unbounded on: centre 0, half-extent infinity.  (The culls' slab tests are
+ * c (1/d) -+ h |1/d| in this form: no minima or maxima per axis, which issue at half rate.) */
+void centre_half(double lo, double hi, float *c, float *h) {
+    if (!std::isfinite(lo) || !std::isfinite(hi)) { *c = 0.0f; *h = INFINITY; return; }
+    const float centre = (float)(0.5 * (lo + hi));
+    const double need = std::max(hi - (double)centre, (double)centre - lo);
+    *c = centre;
+    *h = std::nextafter((float)std::max(need, 0.0), INFINITY);
+    if ((double)*h < need) *h = std::nextafter(*h, INFINITY);
+}
+double box_lo(const Quad &centre, const Quad &half, int k) { return (double)centre.v[k] - (double)half.v[k]; }    /* (-infinity for an unbounded axis) */
+double box_hi(const Quad &centre, const Quad &half, int k) { return (double)centre.v[k] + (double)half.v[k]; }
+
 /* axis of a +-unit axis vector (other components exactly +-0), or -1 */
 int unit_axis(const float v[3], float *sign) {
     for (int k = 0; k < 3; ++k)
@@ -301,7 +315,7 @@ bool shadow_voxels(const std::vector<Quad> &items, int first_leaf, const std::ve
     double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
     for (int i = first_leaf; i < n_items; ++i)
         for (int k = 0; k < 3; ++k) {
-            const double a = items[(size_t)2 * i].v[k], b = items[(size_t)2 * i + 1].v[k];
+            const double a = box_lo(items[(size_t)2 * i], items[(size_t)2 * i + 1], k), b = box_hi(items[(size_t)2 * i], items[(size_t)2 * i + 1], k);
             if (!std::isfinite(a) || !std::isfinite(b)) return false;
             glo[k] = std::min(glo[k], a);
             ghi[k] = std::max(ghi[k], b);
@@ -311,7 +325,7 @@ bool shadow_voxels(const std::vector<Quad> &items, int first_leaf, const std::ve
     for (int k = 0; k < 3; ++k) {
         double lo = glo[k], hi = ghi[k];
         for (int i = 0; i < first_leaf; ++i) {
-            const double a = items[(size_t)2 * i].v[k], b = items[(size_t)2 * i + 1].v[k];
+            const double a = box_lo(items[(size_t)2 * i], items[(size_t)2 * i + 1], k), b = box_hi(items[(size_t)2 * i], items[(size_t)2 * i + 1], k);
             if (std::isfinite(a)) lo = std::min(lo, a);
             if (std::isfinite(b)) hi = std::max(hi, b);
         }
@@ -362,8 +376,8 @@ bool shadow_voxels(const std::vector<Quad> &items, int first_leaf, const std::ve
                 for (int i = first_leaf; i < n_items; ++i) {
                     double far = 0.0, blo[3], bhi[3];
                     for (int k = 0; k < 3; ++k) {
-                        blo[k] = items[(size_t)2 * i].v[k];
-                        bhi[k] = items[(size_t)2 * i + 1].v[k];
+                        blo[k] = box_lo(items[(size_t)2 * i], items[(size_t)2 * i + 1], k);
+                        bhi[k] = box_hi(items[(size_t)2 * i], items[(size_t)2 * i + 1], k);
                         far += std::max(std::max(std::fabs(blo[k] - vlo[k]), std::fabs(blo[k] - vhi[k])),
                                         std::max(std::fabs(bhi[k] - vlo[k]), std::fabs(bhi[k] - vhi[k])));
                     }
@@ -580,8 +594,8 @@ int pack_scene(rt_scene *s) {
             Quad q0, q1;
             for (int k = 0; k < 3; ++k) {
                 const bool ok = !unbounded && std::isfinite(lo[k]) && std::isfinite(hi[k]) && std::isfinite(pad);
-                q0.v[k] = ok ? std::nextafter((float)(lo[k] - pad), -INF) : -INF;
-                q1.v[k] = ok ? std::nextafter((float)(hi[k] + pad), INF) : INF;
+                centre_half(ok ? (double)std::nextafter((float)(lo[k] - pad), -INF) : -(double)INF,
+                            ok ? (double)std::nextafter((float)(hi[k] + pad), INF) : (double)INF, &q0.v[k], &q1.v[k]);
             }
             q0.v[3] = bits_to_float(bits);
             q1.v[3] = bits_to_float(word1);
@@ -653,9 +667,9 @@ int pack_scene(rt_scene *s) {
         for (int i = 0; i < n; ++i)
             if (!clustered[(size_t)i]) object_item(near_items, i);
         auto leaf_item = [&](std::vector<Quad> &out, const LeafItem &l) {
-            Quad q0 = {{l.lo[0], l.lo[1], l.lo[2],
-                        bits_to_float((uint32_t)RT_KIND_SPHERE_LEAF | (l.count << 8) | (l.member_off << 16))}};
-            Quad q1 = {{l.hi[0], l.hi[1], l.hi[2], bits_to_float((uint32_t)(cidx_off * 4) + l.cidx_slot)}};
+            Quad q0 = {{0, 0, 0, bits_to_float((uint32_t)RT_KIND_SPHERE_LEAF | (l.count << 8) | (l.member_off << 16))}};
+            Quad q1 = {{0, 0, 0, bits_to_float((uint32_t)(cidx_off * 4) + l.cidx_slot)}};
+            for (int k = 0; k < 3; ++k) centre_half((double)l.lo[k], (double)l.hi[k], &q0.v[k], &q1.v[k]);
             out.push_back(q0);
             out.push_back(q1);
         };
@@ -933,8 +947,8 @@ bool primary_table(const rt_scene *s, const rt_camera_desc *cam, int W, int H, u
          * side of the eye is as good as unbounded */
         double lo[3], hi[3], far[3], far_sum = 0.0;
         for (int k = 0; k < 3; ++k) {
-            lo[k] = std::isfinite((double)b0.v[k]) ? (double)b0.v[k] : eye[k] - 7.0e4;
-            hi[k] = std::isfinite((double)b1.v[k]) ? (double)b1.v[k] : eye[k] + 7.0e4;
+            lo[k] = std::isfinite(box_lo(b0, b1, k)) ? box_lo(b0, b1, k) : eye[k] - 7.0e4;
+            hi[k] = std::isfinite(box_hi(b0, b1, k)) ? box_hi(b0, b1, k) : eye[k] + 7.0e4;
             lo[k] = std::max(lo[k], eye[k] - 7.0e4); hi[k] = std::min(hi[k], eye[k] + 7.0e4);
             far[k] = std::max(std::fabs(lo[k] - eye[k]), std::fabs(hi[k] - eye[k]));
             far_sum += far[k];

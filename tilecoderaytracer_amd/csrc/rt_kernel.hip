@@ -537,18 +537,19 @@ __device__ __forceinline__ bool ray_is_finite(const V3 o, const V3 d) {
  * below is written so that a NaN bound means "needed".
  * Lanes that do not need a box may still run its member tests (the guard is
  * wave-level); by the argument above those tests find nothing. */
-__device__ __forceinline__ bool box_needed(const float4 b0, const float4 b1, const V3 o, const V3 inv,
+__device__ __forceinline__ bool box_needed(const float4 centre, const float4 half, const V3 o, const V3 inv,
                                            const float max_dist) {
-    const float x0 = b0.x - o.x, x1 = b1.x - o.x;
-    const float y0 = b0.y - o.y, y1 = b1.y - o.y;
-    const float z0 = b0.z - o.z, z1 = b1.z - o.z;
-    const float far = fmaxf(fabsf(x0), fabsf(x1)) + fmaxf(fabsf(y0), fabsf(y1)) + fmaxf(fabsf(z0), fabsf(z1));
+    /* The box comes as centre and half-extent (rt_tables.h): the slab of axis k is t in c_k (1/d_k) -+ (h_k + slack) |1/d_k| with
+     * c = centre - o -- no minimum or maximum per axis (those issue at half rate: Roofline in DESIGN.md), and the L1 distance to
+     * the farthest corner is the sum of |c_k| + h_k.  (A direction component of exactly 0 gives +-infinity -+ infinity = NaN, which
+     * the minima and maxima below skip: that axis then does not constrain -- conservative.) */
+    const float cx = centre.x - o.x, cy = centre.y - o.y, cz = centre.z - o.z;
+    const float far = ((fabsf(cx) + half.x) + (fabsf(cy) + half.y)) + (fabsf(cz) + half.z);
     const float ex = RT_SPHERE_SLACK * far;
-    const float ax = (x0 - ex) * inv.x, bx = (x1 + ex) * inv.x;
-    const float ay = (y0 - ex) * inv.y, by = (y1 + ex) * inv.y;
-    const float az = (z0 - ex) * inv.z, bz = (z1 + ex) * inv.z;
-    const float t_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float t_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float tcx = cx * inv.x, tcy = cy * inv.y, tcz = cz * inv.z;
+    const float tgx = (half.x + ex) * fabsf(inv.x), tgy = (half.y + ex) * fabsf(inv.y), tgz = (half.z + ex) * fabsf(inv.z);
+    const float t_enter = fmaxf(fmaxf(tcx - tgx, tcy - tgy), tcz - tgz);
+    const float t_exit = fminf(fminf(tcx + tgx, tcy + tgy), tcz + tgz);
     /* no intersection (t_exit < t_enter), exit behind the origin (t_exit < 0) or entry beyond max_dist, each with the slab
      * arithmetic's tolerance -- as ONE margin: the three conditions share the tolerance, so it is added to their minimum (a
      * v_min3), and a NaN anywhere leaves the margin a NaN or positive: "needed" */
@@ -968,9 +969,10 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
         if (cull) {
             const int mine = min(base + lane, p.n_near_items - 1);
             const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
-            float ax = b0.x - omaxx, bx = b1.x - ominx;
-            float ay = b0.y - omaxy, by = b1.y - ominy;
-            float az = b0.z - omaxz, bz = b1.z - ominz;
+            /* (b0: the box's centre, b1: its half-extent) */
+            float ax = (b0.x - b1.x) - omaxx, bx = (b0.x + b1.x) - ominx;
+            float ay = (b0.y - b1.y) - omaxy, by = (b0.y + b1.y) - ominy;
+            float az = (b0.z - b1.z) - omaxz, bz = (b0.z + b1.z) - ominz;
             /* a plane's hit point is off its ray by rounding only; a sphere's box has to hold the coarse float test */
             float ex, ey, ez;
             RT_CULL_SLACK(__float_as_uint(b0.w), fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fabsf(ay), fabsf(by)), fmaxf(fabsf(az), fabsf(bz)), ex, ey, ez);
@@ -1119,11 +1121,11 @@ __device__ __forceinline__ unsigned long long shadow_cull_two_lights(const float
     const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
     const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
     const float gx = (half.x + grow) + more, gy = (half.y + grow) + more, gz = (half.z + grow) + more;
-    const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
-    const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
-    const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
-    const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    /* b0: the item box's centre, b1: its half-extent: the slab of axis k is (centre - c) / seg -+ (half + grown) / |seg| */
+    const float tcx = (b0.x - c.x) * sinv.x, tcy = (b0.y - c.y) * sinv.y, tcz = (b0.z - c.z) * sinv.z;
+    const float tgx = (b1.x + gx) * fabsf(sinv.x), tgy = (b1.y + gy) * fabsf(sinv.y), tgz = (b1.z + gz) * fabsf(sinv.z);
+    const float s_enter = fmaxf(fmaxf(tcx - tgx, tcy - tgy), tcz - tgz);
+    const float s_exit = fminf(fminf(tcx + tgx, tcy + tgy), tcz + tgz);
     /* every comparison is false on a NaN, which then means "candidate" */
     const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
                        (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
@@ -1272,11 +1274,11 @@ __device__ __forceinline__ bool in_shade(const RtParams &p, const float4 *lds, f
             const float4 b0 = items[2 * mine], b1 = items[2 * mine + 1];
             const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
             const float gx = e.x + more, gy = e.y + more, gz = e.z + more;
-            const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
-            const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
-            const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
-            const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-            const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            /* b0: the item box's centre, b1: its half-extent: the slab of axis k is (centre - c) / seg -+ (half + grown) / |seg| */
+            const float tcx = (b0.x - c.x) * sinv.x, tcy = (b0.y - c.y) * sinv.y, tcz = (b0.z - c.z) * sinv.z;
+            const float tgx = (b1.x + gx) * fabsf(sinv.x), tgy = (b1.y + gy) * fabsf(sinv.y), tgz = (b1.z + gz) * fabsf(sinv.z);
+            const float s_enter = fmaxf(fmaxf(tcx - tgx, tcy - tgy), tcz - tgz);
+            const float s_exit = fminf(fminf(tcx + tgx, tcy + tgy), tcz + tgz);
             /* every comparison is false on a NaN, which then means "candidate" */
             const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
                                (s_exit < -1.0e-4f) || (s_enter > 1.0001f);
@@ -1510,9 +1512,10 @@ __device__ __forceinline__ void nearest_hit_fast(const RtParams &p, const float4
         } else {
             const int mine = min(base + lane, n_items - 1);
             const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
-            float ax = b0.x - ohi.x, bx = b1.x - olo.x;
-            float ay = b0.y - ohi.y, by = b1.y - olo.y;
-            float az = b0.z - ohi.z, bz = b1.z - olo.z;
+            /* (b0: the box's centre, b1: its half-extent) */
+            float ax = (b0.x - b1.x) - ohi.x, bx = (b0.x + b1.x) - olo.x;
+            float ay = (b0.y - b1.y) - ohi.y, by = (b0.y + b1.y) - olo.y;
+            float az = (b0.z - b1.z) - ohi.z, bz = (b0.z + b1.z) - olo.z;
             float ex, ey, ez;
             RT_CULL_SLACK(__float_as_uint(b0.w), fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fabsf(ay), fabsf(by)), fmaxf(fabsf(az), fabsf(bz)), ex, ey, ez);
             ax -= ex; ay -= ey; az -= ez; bx += ex; by += ey; bz += ez;
@@ -1595,11 +1598,11 @@ __device__ __forceinline__ bool in_shade_fast(const RtParams &p, const float4 *l
         const float4 b0 = boxes[2 * mine], b1 = boxes[2 * mine + 1];
         const float more = (__float_as_uint(b0.w) & RT_ITEM_TIGHT) != 0u ? 0.0f : grow_more;
         const float gx = e.x + more, gy = e.y + more, gz = e.z + more;
-        const float ax = ((b0.x - c.x) - gx) * sinv.x, bx = ((b1.x - c.x) + gx) * sinv.x;
-        const float ay = ((b0.y - c.y) - gy) * sinv.y, by = ((b1.y - c.y) + gy) * sinv.y;
-        const float az = ((b0.z - c.z) - gz) * sinv.z, bz = ((b1.z - c.z) + gz) * sinv.z;
-        const float s_enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float s_exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        /* b0: the item box's centre, b1: its half-extent: the slab of axis k is (centre - c) / seg -+ (half + grown) / |seg| */
+        const float tcx = (b0.x - c.x) * sinv.x, tcy = (b0.y - c.y) * sinv.y, tcz = (b0.z - c.z) * sinv.z;
+        const float tgx = (b1.x + gx) * fabsf(sinv.x), tgy = (b1.y + gy) * fabsf(sinv.y), tgz = (b1.z + gz) * fabsf(sinv.z);
+        const float s_enter = fmaxf(fmaxf(tcx - tgx, tcy - tgy), tcz - tgz);
+        const float s_exit = fminf(fminf(tcx + tgx, tcy + tgy), tcz + tgz);
         /* every comparison is false on a NaN, which then means "candidate" */
         const bool apart = (s_exit < s_enter - 1.0e-4f * (fabsf(s_enter) + fabsf(s_exit)) - 1.0e-6f) ||
                            (s_exit < -1.0e-4f) || (s_enter > 1.0001f);

@@ -41,8 +41,9 @@
  * the scan range (src/RayTracer.cpp:709-739) -- walk a table of ITEMS: one per
  * object that is not in a clustered run, in Scene index order, then one per
  * LEAF of each clustered run.  2 quads per item:
- *   {box lo.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
- *   {box hi.xyz, bits(Scene index | quad offset of the full 5-quad plane record << 12)}
+ *   {box CENTRE.xyz, bits(kind | count << 8 | geometry quad offset << 16)},
+ *   {box HALF-EXTENT.xyz, bits(Scene index | quad offset of the full 5-quad plane record << 12)}
+ * (the box is [centre - half, centre + half]; an axis the item is unbounded on: centre 0, half-extent infinity)
  * kind = RT_KIND_SPHERE / _INFINITE_PLANE / _FINITE_PLANE;
  *        RT_KIND_FINITE_AA + normal axis for an axis-aligned rectangle (geometry
  *        offset = its aa record);
@@ -214,7 +215,7 @@ typedef struct RtParams {
  * the scan range), then the others; within each part sorted by kind.  Neither scan depends on the order: the
  * shadow verdict is an OR (src/RayTracer.cpp:727-729), the nearest hit the minimum of (distance, Scene index)
  * (:71-80).  Per item i:
- *   box      2 quads {lo.xyz, bits(kind | RT_ITEM_TIGHT)}, {hi.xyz, control word}: what the wavefront culls test
+ *   box      2 quads {centre.xyz, bits(kind | RT_ITEM_TIGHT)}, {half-extent.xyz, control word}: what the wavefront culls test
  *   record   2 quads, all the exact test reads, so that a candidate costs ONE LDS round trip:
  *              sphere          {c.xyz, r^2}, {-}
  *              infinite plane  {n.xyz, distance_to_origin}, {-}
