@@ -629,6 +629,26 @@ def test_shadow_voxels_on_the_sphere_grids(oracle, name, W, H, depth, svox):
     assert_same(r.render(W, H, depth), oracle.OracleScene.named(name).render(W, H, depth), f"{name} svox={svox}")
 
 
+def test_shadow_voxels_take_candidates_away(oracle):
+    """What the table is for (counting build, 1 024-sphere grid, 512^2): the leaves a shadow scan's bundle cull leaves as candidates
+    -- each a box test for the whole wavefront -- drop to less than 0.55 of what they were (at 512^2, whose tiles span twice the scene
+    of a 1024^2 frame's: 11.9 -> 5.7 per scan; 1024^2: 8.9 -> 4.4, the review's mark being five), with the same image, the same rays and
+    no more leaves that some lane needs."""
+    want = oracle.OracleScene.named("grid32").render(512, 512, 4)
+    r = Renderer(HostScene.named("grid32"))
+    img_on, on = r.render_stats(512, 512, 4)
+    r.set_option("svox", 0)
+    img_off, off = r.render_stats(512, 512, 4)
+    assert_same(img_on, want, "grid32 counting build, table on")
+    assert_same(img_off, want, "grid32 counting build, table off")
+    assert on["shadow_rays"] == off["shadow_rays"] and on["wave_shadow_scans"] == off["wave_shadow_scans"]
+    per_scan_on = on["shadow_candidates"] / on["wave_shadow_scans"]
+    per_scan_off = off["shadow_candidates"] / off["wave_shadow_scans"]
+    assert per_scan_off > 7.0 and per_scan_on < 0.55 * per_scan_off and per_scan_on < 6.5, (per_scan_on, per_scan_off)
+    assert on["wave_box_tests"] < 0.75 * off["wave_box_tests"]
+    assert on["shadow_leaves_union"] <= off["shadow_leaves_union"]
+
+
 @pytest.mark.parametrize("seed,n", [(1, 64), (3, 200), (4, 333), (11, 700), (12, 1000)])
 def test_shadow_voxels_on_random_sphere_fields(oracle, seed, n):
     """The same on clustered fields of spheres of mixed sizes with the lights INSIDE the field's box, seen to the horizon: shading
