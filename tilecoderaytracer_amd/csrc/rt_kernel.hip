@@ -884,6 +884,31 @@ __device__ __forceinline__ void flush_near_pairs(const float4 *lds, NearPairs &p
     const int members = has ? count : 0;                  /* of this slot's leaf; none without a pair */
     float pair_t = 65535.0f;
     int pair_idx = -1;
+#if RT_NEAR_FLUSH_TWO
+    /* two members side by side: one gate for both square roots, one for both updates */
+    for (int i = 0; wave_any(i < members); i += 2) {
+        int j0 = i + rot, j1 = i + 1 + rot;
+        j0 = j0 >= count ? j0 - count : j0; j1 = j1 >= count ? j1 - count : j1;
+        j1 = (i + 1 < count) ? j1 : j0;                                /* (an odd leaf's last member twice: the same (distance, index)) */
+        if constexpr (kStats) { for (int k = 0; k < 2; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i + k < members); st_wave(st, ST_NEAREST_SPHERE); } }
+        const float4 s0 = lds[geom + j0], s1 = lds[geom + j1];
+        const V3 e0 = mk(s0.x - po.x, s0.y - po.y, s0.z - po.z), e1 = mk(s1.x - po.x, s1.y - po.y, s1.z - po.z);
+        const float v0 = dot3(e0, pd), v1 = dot3(e1, pd);
+        const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);
+        const float m0 = sphere_margin(v0, q0), m1 = sphere_margin(v1, q1);
+        if (wave_any(__builtin_fmaxf(m0, m1) >= 0.0f)) {
+            float t0, t1;
+            if (wave_any(!sphere_operands_plain(fabsf(q0) + fabsf(q1)))) { t0 = sphere_hit_or_inf_exact(v0, q0); t1 = sphere_hit_or_inf_exact(v1, q1); }
+            else { t0 = sphere_hit_or_inf(v0, sqrt_in_range(q0), m0); t1 = sphere_hit_or_inf(v1, sqrt_in_range(q1), m1); }
+            t0 = (i < members) ? t0 : __builtin_huge_valf();
+            t1 = (i + 1 < members) ? t1 : __builtin_huge_valf();
+            if (wave_any(__builtin_fminf(t0, t1) <= pair_t)) {
+                take_nearer(t0, (int)lds_u32[pb.ids + j0], &pair_t, &pair_idx);
+                take_nearer(t1, (int)lds_u32[pb.ids + j1], &pair_t, &pair_idx);
+            }
+        }
+    }
+#else
     for (int i = 0; wave_any(i < members); ++i) {
         int j = i + rot;
         j = j >= count ? j - count : j;
@@ -893,6 +918,7 @@ __device__ __forceinline__ void flush_near_pairs(const float4 *lds, NearPairs &p
         t = (i < members) ? t : __builtin_huge_valf();
         if (wave_any(t <= pair_t)) take_nearer(t, (int)lds_u32[pb.ids + j], &pair_t, &pair_idx);
     }
+#endif
     /* back to the rays' lanes, push by push */
     float best = *best_io;
     int best_idx = *best_idx_io;
@@ -1161,6 +1187,9 @@ __device__ __forceinline__ unsigned long long shadow_cull_two_lights(const float
  * 1 % to it).  profiles/r03_experiments.txt, 14. */
 #ifndef RT_NT_STORES
 #define RT_NT_STORES 1           /* the image leaves through streaming stores (HBM bytes per built-in frame 272 -> 241 MB) */
+#endif
+#ifndef RT_NEAR_FLUSH_TWO
+#define RT_NEAR_FLUSH_TWO 1     /* the nearest-hit pair flush tests two members side by side (grid-32 3.550 -> 3.530 ms, without shadows 1.828 -> 1.810, grid-16 d8 3.813 -> 3.800; r04_experiments 19) */
 #endif
 #ifndef RT_FLUSH_TWO_ABREAST
 #define RT_FLUSH_TWO_ABREAST 1     /* the 80-register kernel's pair flush tests two members abreast (four: 23 spilled registers, grid-32 3.68 -> 3.73 ms; two: 7, 3.68 -> 3.64; r04_experiments 14) */
