@@ -291,6 +291,21 @@ __device__ __forceinline__ float four_spheres_nearest_vq(const float v0, const f
     const float q2 = s2.w - (dot3(e2, e2) - v2 * v2), q3 = s3.w - (dot3(e3, e3) - v3 * v3);                                \
     const float m0 = sphere_margin(v0, q0), m1 = sphere_margin(v1, q1), m2 = sphere_margin(v2, q2), m3 = sphere_margin(v3, q3)
 
+/* two sphere tests side by side, for the nearest-hit scans: the distances the two report (+infinity: no hit) */
+__device__ __forceinline__ void two_spheres_distances(const float4 s0, const float4 s1, const V3 o, const V3 d, float *t0_out, float *t1_out) {
+    const V3 e0 = mk(s0.x - o.x, s0.y - o.y, s0.z - o.z), e1 = mk(s1.x - o.x, s1.y - o.y, s1.z - o.z);
+    const float v0 = dot3(e0, d), v1 = dot3(e1, d);
+    const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);
+    const float m0 = sphere_margin(v0, q0), m1 = sphere_margin(v1, q1);
+    float t0 = __builtin_huge_valf(), t1 = t0;
+    if (wave_any(__builtin_fmaxf(m0, m1) >= 0.0f)) {
+        if (wave_any(!sphere_operands_plain(fabsf(q0) + fabsf(q1)))) { t0 = sphere_hit_or_inf_exact(v0, q0); t1 = sphere_hit_or_inf_exact(v1, q1); }
+        else { t0 = sphere_hit_or_inf(v0, sqrt_in_range(q0), m0); t1 = sphere_hit_or_inf(v1, sqrt_in_range(q1), m1); }
+    }
+    *t0_out = t0;
+    *t1_out = t1;
+}
+
 /* BLOCKED WITHOUT THE SQUARE ROOT.  A shadow scan does not want the distance a sphere reports, only whether it is below the
  * distance to the light (src/RayTracer.cpp:727-729), and for nearly every sphere that a shadow ray meets that is plain from v:
  * the reported distance is root1 = fl(v - sqrt(q)) <= v, so a candidate (margin >= 0) with
@@ -891,21 +906,13 @@ __device__ __forceinline__ void flush_near_pairs(const float4 *lds, NearPairs &p
         j0 = j0 >= count ? j0 - count : j0; j1 = j1 >= count ? j1 - count : j1;
         j1 = (i + 1 < count) ? j1 : j0;                                /* (an odd leaf's last member twice: the same (distance, index)) */
         if constexpr (kStats) { for (int k = 0; k < 2; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, i + k < members); st_wave(st, ST_NEAREST_SPHERE); } }
-        const float4 s0 = lds[geom + j0], s1 = lds[geom + j1];
-        const V3 e0 = mk(s0.x - po.x, s0.y - po.y, s0.z - po.z), e1 = mk(s1.x - po.x, s1.y - po.y, s1.z - po.z);
-        const float v0 = dot3(e0, pd), v1 = dot3(e1, pd);
-        const float q0 = s0.w - (dot3(e0, e0) - v0 * v0), q1 = s1.w - (dot3(e1, e1) - v1 * v1);
-        const float m0 = sphere_margin(v0, q0), m1 = sphere_margin(v1, q1);
-        if (wave_any(__builtin_fmaxf(m0, m1) >= 0.0f)) {
-            float t0, t1;
-            if (wave_any(!sphere_operands_plain(fabsf(q0) + fabsf(q1)))) { t0 = sphere_hit_or_inf_exact(v0, q0); t1 = sphere_hit_or_inf_exact(v1, q1); }
-            else { t0 = sphere_hit_or_inf(v0, sqrt_in_range(q0), m0); t1 = sphere_hit_or_inf(v1, sqrt_in_range(q1), m1); }
-            t0 = (i < members) ? t0 : __builtin_huge_valf();
-            t1 = (i + 1 < members) ? t1 : __builtin_huge_valf();
-            if (wave_any(__builtin_fminf(t0, t1) <= pair_t)) {
-                take_nearer(t0, (int)lds_u32[pb.ids + j0], &pair_t, &pair_idx);
-                take_nearer(t1, (int)lds_u32[pb.ids + j1], &pair_t, &pair_idx);
-            }
+        float t0, t1;
+        two_spheres_distances(lds[geom + j0], lds[geom + j1], po, pd, &t0, &t1);
+        t0 = (i < members) ? t0 : __builtin_huge_valf();
+        t1 = (i + 1 < members) ? t1 : __builtin_huge_valf();
+        if (wave_any(__builtin_fminf(t0, t1) <= pair_t)) {
+            take_nearer(t0, (int)lds_u32[pb.ids + j0], &pair_t, &pair_idx);
+            take_nearer(t1, (int)lds_u32[pb.ids + j1], &pair_t, &pair_idx);
         }
     }
 #else
@@ -1073,8 +1080,22 @@ __device__ __forceinline__ void nearest_hit_items(const RtParams &p, const float
                     continue;
                 }
                 const uint32_t *ids = lds_u32 + bits1;
+#if RT_NEAR_DIRECT_TWO
+                int i = 0;
+                for (; i + 2 <= n; i += 2) {
+                    if constexpr (kStats) { for (int k = 0; k < 2; ++k) { st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs); st_wave(st, ST_NEAREST_SPHERE); if (stat_unculled) st_wave(st, ST_NEAREST_UNCULLED_SPHERE); } }
+                    float t0, t1;
+                    two_spheres_distances(g[i], g[i + 1], o, d, &t0, &t1);
+                    if (wave_any(__builtin_fminf(t0, t1) <= best)) {
+                        take_nearer(t0, (int)ids[i], &best, &best_idx);
+                        take_nearer(t1, (int)ids[i + 1], &best, &best_idx);
+                    }
+                }
+                for (; i < n; ++i) {
+#else
 #pragma unroll 2
                 for (int i = 0; i < n; ++i) {
+#endif
                     st_wave(st, ST_WAVE_SPHERE_TESTS); st_lane(st, ST_LANE_SPHERE_TESTS, lane_needs);
                     st_wave(st, ST_NEAREST_SPHERE); if (stat_unculled) st_wave(st, ST_NEAREST_UNCULLED_SPHERE);
                     t = sphere_hit_distance(g[i], o, d);
@@ -1187,6 +1208,9 @@ __device__ __forceinline__ unsigned long long shadow_cull_two_lights(const float
  * 1 % to it).  profiles/r03_experiments.txt, 14. */
 #ifndef RT_NT_STORES
 #define RT_NT_STORES 1           /* the image leaves through streaming stores (HBM bytes per built-in frame 272 -> 241 MB) */
+#endif
+#ifndef RT_NEAR_DIRECT_TWO
+#define RT_NEAR_DIRECT_TWO 1    /* a leaf that most lanes need: its members two side by side in the nearest-hit scan too (-0.2 ... -0.7 %) */
 #endif
 #ifndef RT_NEAR_FLUSH_TWO
 #define RT_NEAR_FLUSH_TWO 1     /* the nearest-hit pair flush tests two members side by side (grid-32 3.550 -> 3.530 ms, without shadows 1.828 -> 1.810, grid-16 d8 3.813 -> 3.800; r04_experiments 19) */
