@@ -266,6 +266,13 @@ __device__ __forceinline__ float sphere_hit_distance(const float4 s, const V3 o,
 #ifndef RT_MEMBERS_ABREAST
 #define RT_MEMBERS_ABREAST 4
 #endif
+/* (both used in the nearest-hit scans further down: defined here, ahead of their first use) */
+#ifndef RT_NEAR_FLUSH_TWO
+#define RT_NEAR_FLUSH_TWO 1     /* the nearest-hit pair flush tests two members side by side (grid-32 3.550 -> 3.530 ms, without shadows 1.828 -> 1.810, grid-16 d8 3.813 -> 3.800; r04_experiments 19) */
+#endif
+#ifndef RT_NEAR_DIRECT_TWO
+#define RT_NEAR_DIRECT_TWO 1    /* a leaf that most lanes need: its members two side by side in the nearest-hit scan too (-0.2 ... -0.7 %) */
+#endif
 /* four sphere tests side by side: the smallest distance any of them reports (+infinity: none hit), from the tests' v, q (= d^2)
  * and margins */
 __device__ __forceinline__ float four_spheres_nearest_vq(const float v0, const float v1, const float v2, const float v3,
@@ -1208,12 +1215,6 @@ __device__ __forceinline__ unsigned long long shadow_cull_two_lights(const float
  * 1 % to it).  profiles/r03_experiments.txt, 14. */
 #ifndef RT_NT_STORES
 #define RT_NT_STORES 1           /* the image leaves through streaming stores (HBM bytes per built-in frame 272 -> 241 MB) */
-#endif
-#ifndef RT_NEAR_DIRECT_TWO
-#define RT_NEAR_DIRECT_TWO 1    /* a leaf that most lanes need: its members two side by side in the nearest-hit scan too (-0.2 ... -0.7 %) */
-#endif
-#ifndef RT_NEAR_FLUSH_TWO
-#define RT_NEAR_FLUSH_TWO 1     /* the nearest-hit pair flush tests two members side by side (grid-32 3.550 -> 3.530 ms, without shadows 1.828 -> 1.810, grid-16 d8 3.813 -> 3.800; r04_experiments 19) */
 #endif
 #ifndef RT_FLUSH_TWO_ABREAST
 #define RT_FLUSH_TWO_ABREAST 1     /* the 80-register kernel's pair flush tests two members abreast (four: 23 spilled registers, grid-32 3.68 -> 3.73 ms; two: 7, 3.68 -> 3.64; r04_experiments 14) */
