@@ -564,13 +564,14 @@ def main(argv=None):
         # N > 1, one launch per strip: where this rank's strip starts handing out its tile rows is learned from one counting frame
         # and a few timed ones (rt_learn_tile_order; scheduling only, the pixels are the same; never loses the run)
         learned = None
-        if world > 1 and chunks == 1 and x1 > x0 and not args.no_learn:
-            try:
-                renderer.learn_tile_order(W, H, depth, x0, x1)
-                learned = True
-            except Exception as e:
-                learned = f"unavailable ({e!r})"
-            fence()
+        if world > 1 and chunks == 1 and not args.no_learn:
+            if x1 > x0:
+                try:
+                    renderer.learn_tile_order(W, H, depth, x0, x1)
+                    learned = True
+                except Exception as e:
+                    learned = f"unavailable ({e!r})"
+            fence()                                   # a rank with an empty strip learns nothing but meets the others' barrier
 
         for _ in range(warm_left):
             pipe.step()
@@ -593,7 +594,7 @@ def main(argv=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, max_frame_kernel_ms = float(t[0]), float(t[1])
         return dict(scene_name=scene_name, W=W, H=H, depth=depth, cfg_note=cfg_note, host=host, renderer=renderer,
-                    x0=x0, x1=x1, strip=pipe.strip, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=max_frame_kernel_ms,
+                    x0=x0, x1=x1, strip=pipe.strip, pipe=pipe, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=max_frame_kernel_ms,
                     launches_per_frame=launches_per_frame, frame_kernel_ms=frame_kernel_ms,
                     partition=pipe.describe(),
                     partition_note=(partition_note or "") + ("; tile rows of every strip start where rt_learn_tile_order measured best" if learned is True
@@ -707,6 +708,21 @@ def main(argv=None):
                         "the kernel is bound by fp32 (non-FMA) instruction issue, see DESIGN.md",
             },
         }
+        if use_dist:
+            # the multi-GPU path's own parity property, measured in this run and outside the timed region: the image the
+            # strips were gathered into on rank 0 is, bit for bit, what ONE GPU renders as one frame (dx = x / W uses the
+            # global x; the one-GPU frame is what tests/test_parity_gpu.py compares with the oracle)
+            try:
+                gathered = m["pipe"].image(W)
+                whole = torch.empty((W, H, 3), dtype=torch.float32, device=dev)
+                renderer.render_device(W, H, depth, 0, W, whole.data_ptr(), stream)
+                torch.cuda.synchronize(dev)
+                differ = int((gathered[:W].view(torch.int32) != whole.view(torch.int32)).any(dim=2).sum())      # bit patterns
+                out["config"]["gathered_image_vs_one_gpu_frame"] = {
+                    "pixels_compared": W * H, "pixels_differing": differ, "identical": differ == 0}
+                del whole
+            except Exception as e:
+                out["config"]["gathered_image_vs_one_gpu_frame"] = {"error": repr(e)}
         if grid is not None:
             out["sphere_grid"] = grid
         if pipelined is not None:

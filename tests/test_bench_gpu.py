@@ -53,6 +53,8 @@ def test_bench_force_dist_runs_the_chunked_single_frame_path_on_one_gpu():
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
     assert "4 column chunks" in j["config"]["partition"] and j["value"] > 10.0
+    # what the chunks were gathered into is the frame one launch renders, bit for bit (bench.py measures that itself on a dist run)
+    assert j["config"]["gathered_image_vs_one_gpu_frame"] == {"pixels_compared": 512 * 512, "pixels_differing": 0, "identical": True}
     r = j["roofline"]
     assert r["kernel"].startswith("rt_render_kernel_clusters")
     # four launches per frame: a launch's share of the pixels over a launch's average duration, which is the frame's
