@@ -377,6 +377,34 @@ def test_4096_grid16_depth8_columns(oracle):
         assert_same(img[x0:x0 + 1], want, f"column {x0}")
 
 
+def _assert_every_pixel(oracle, img, make_oracle_scene, depth, what):
+    """All 4096 x 4096 pixels of `img` against the oracle, 64 column blocks dealt to the host's cores
+    (the C oracle releases the GIL; one scene per worker call)."""
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(16, len(os.sched_getaffinity(0))))
+    bounds = [(k * 64, (k + 1) * 64) for k in range(64)]
+
+    def work(b):
+        return make_oracle_scene().render(4096, 4096, depth, b[0], b[1])
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for (x0, x1), want in zip(bounds, pool.map(work, bounds)):
+            assert_same(img[x0:x1], want, f"{what}: columns {x0}:{x1}")
+
+
+def test_4096_grid32_depth4_every_pixel(oracle):
+    """configs[2] (1 024 spheres, shadow scan on), the frame bench.py's `sphere_grid` line times: all 16.7 M pixels
+    against the oracle (about 10 core-minutes of oracle: 40 s on the GPU box's 16 cores)."""
+    img = Renderer(HostScene.grid(32, True)).render(4096, 4096, 4)
+    _assert_every_pixel(oracle, img, lambda: oracle.OracleScene.grid(32, True), 4, "grid-32 depth 4")
+
+
+def test_4096_grid16_depth8_every_pixel(oracle):
+    """configs[4] (256 spheres, depth 8): all 16.7 M pixels against the oracle."""
+    img = Renderer(HostScene.grid(16, True)).render(4096, 4096, 8)
+    _assert_every_pixel(oracle, img, lambda: oracle.OracleScene.grid(16, True), 8, "grid-16 depth 8")
+
+
 def test_render_device_into_torch_memory(oracle):
     """The device-pointer entry point used by bench.py and the multi-GPU path."""
     import torch
