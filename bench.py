@@ -723,6 +723,15 @@ def main(argv=None):
                 del whole
             except Exception as e:
                 out["config"]["gathered_image_vs_one_gpu_frame"] = {"error": repr(e)}
+        if world > 1:
+            # what bounds a single frame on N GPUs, in the line itself: every peer's columns cross ONE xGMI link into rank 0
+            peer_mb = BYTES_PER_PIXEL * W * H * (world - 1) / world / 1e6
+            out["config"]["scaling_note"] = (
+                f"single-frame delivery moves {peer_mb:.0f} MB ({world - 1} strips of 12 B/pixel) into rank 0 per frame, each peer over its own "
+                f"point-to-point xGMI link; frame kernel time of the slowest rank {m['max_kernel_ms']:.3f} ms of {elapsed / args.steps * 1e3:.3f} ms per step: "
+                "where the strips render faster than their columns travel (the built-in scene: 0.6 ms of rendering in all) the figure is "
+                "transfer-bound whatever the partition -- `sphere_grid` is the north star's scaling scene, `pipelined` the throughput "
+                "with the transfers hidden")
         if grid is not None:
             out["sphere_grid"] = grid
         if pipelined is not None:
