@@ -33,8 +33,9 @@
 extern "C" {
 #endif
 
-#define RT_CAPI_VERSION 3      /* 3: strips cut by measured cost (rt_multi_render chunks = 0, rt_balance_strips, rt_suggest_chunks,
-                                * rt_multi_set_bounds, rt_multi_get_info); options, counters and calibration moved to rt_capi_tuning.h */
+#define RT_CAPI_VERSION 4      /* 3: strips cut by measured cost (rt_multi_render chunks = 0, rt_balance_strips, rt_suggest_chunks,
+                                * rt_multi_set_bounds, rt_multi_get_info); options, counters and calibration moved to rt_capi_tuning.h
+                                * 4: rt_shared_image_* (one image in one GPU's HBM that the other GPUs' processes render into) */
 
 enum {
     RT_OK = 0,
@@ -201,6 +202,23 @@ int rt_chunk_bounds(int x0, int x1, int chunks, int k, int align, int *a, int *b
  * the column stride of the strips in the gathered buffer (rank g at g * width: only trailing strips
  * are short, so columns [0, W) are contiguous at its start).  Returns 0 on bad arguments. */
 int rt_strip_bounds(int W, int ngpu, int g, int *x0, int *x1);
+
+/* Replaces: the one `pixels` array that every rank of the reference writes into while it renders
+ * (src/RayTracer.h:44; src/RayTracer.cpp:904-923, 1188-1196: the Tilera tiles share that memory) -- for one process per GPU.
+ * The process that owns the frame creates it in ITS GPU's HBM (rt_shared_image_create: `bytes` of device memory, a
+ * hipMalloc of its own, and the 64-byte handle that names it); the handle travels to the other processes of the node by
+ * whatever channel they have (a pipe, a file, torch.distributed); each maps the image (rt_shared_image_open, on the GPU it
+ * renders with) and passes `mapped + (size_t)x0 * H * 3 * sizeof(float)` as rt_render_device's d_out_rgb: the kernel's
+ * pixel stores travel over xGMI into the owner's HBM as they are issued -- no strip buffer, no gather step, nothing for
+ * the owner's GPU to do.  A strip is complete, and visible to the owner, when the stream it was rendered on has drained
+ * (hipStreamSynchronize / an event): tell the owner then, by the same channel.  The owner renders its own columns through
+ * the pointer rt_shared_image_create gave it.  close: a mapping of rt_shared_image_open; destroy: the owner's allocation,
+ * after every mapping is closed.  int returns as everywhere (RT_OK, else rt_last_error()). */
+#define RT_SHARED_HANDLE_BYTES 64
+int rt_shared_image_create(int device, uint64_t bytes, void **d_image, unsigned char handle[RT_SHARED_HANDLE_BYTES]);
+int rt_shared_image_open(int device, const unsigned char handle[RT_SHARED_HANDLE_BYTES], void **d_image);
+int rt_shared_image_close(int device, void *d_image);
+int rt_shared_image_destroy(int device, void *d_image);
 
 int rt_get_timing(const rt_scene *scene, rt_timing *out);
 int rt_reset_timing(rt_scene *scene);

@@ -21,6 +21,7 @@ def declared_functions(header="rt_capi.h"):
 DROP_IN = ["rt_balance_strips", "rt_capi_version", "rt_chunk_bounds", "rt_device_count", "rt_get_timing", "rt_last_error",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_get_info", "rt_multi_render", "rt_multi_set_bounds",
            "rt_render", "rt_render_device", "rt_render_multi", "rt_reset_timing", "rt_scene_create", "rt_scene_destroy",
+           "rt_shared_image_close", "rt_shared_image_create", "rt_shared_image_destroy", "rt_shared_image_open",
            "rt_strip_bounds", "rt_suggest_chunks"]
 TUNING = ["rt_capi_tuning_version", "rt_get_launch_info", "rt_get_timeline", "rt_learn_tile_order", "rt_multi_set_option",
           "rt_render_stats", "rt_set_option"]
@@ -53,7 +54,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load_library()
     for name in declared_functions("rt_capi.h") + declared_functions("rt_capi_tuning.h"):
         assert getattr(lib, name) is not None, name
-    assert lib.rt_capi_version() == 3 and lib.rt_capi_tuning_version() == 1
+    assert lib.rt_capi_version() == 4 and lib.rt_capi_tuning_version() == 1
     for header, macro, fn in (("rt_capi.h", "RT_CAPI_VERSION", lib.rt_capi_version),
                               ("rt_capi_tuning.h", "RT_CAPI_TUNING_VERSION", lib.rt_capi_tuning_version)):
         text = open(os.path.join(ROOT, "include", header)).read()

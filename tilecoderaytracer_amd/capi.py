@@ -127,6 +127,10 @@ def load_library():
     lib.rt_balance_strips.argtypes = [i, i, C.POINTER(i), C.POINTER(C.c_double), C.c_double, i, C.POINTER(i)]
     lib.rt_suggest_chunks.argtypes = [C.c_double, C.c_double, i]
     lib.rt_capi_tuning_version.restype = i
+    lib.rt_shared_image_create.argtypes = [i, C.c_uint64, C.POINTER(vp), C.c_char_p]
+    lib.rt_shared_image_open.argtypes = [i, C.c_char_p, C.POINTER(vp)]
+    lib.rt_shared_image_close.argtypes = [i, vp]
+    lib.rt_shared_image_destroy.argtypes = [i, vp]
     lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_render_stats.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i, vp, C.POINTER(C.c_uint64), i, vp, i]
     lib.rt_learn_tile_order.argtypes = [vp, C.POINTER(RtCameraDesc), i, i, i, i, i]
@@ -140,7 +144,8 @@ def load_library():
                  "rt_render_device", "rt_render_multi", "rt_render_stats", "rt_learn_tile_order", "rt_get_timing", "rt_reset_timing",
                  "rt_get_launch_info", "rt_set_option", "rt_chunk_bounds", "rt_multi_create", "rt_multi_render",
                  "rt_multi_set_option", "rt_multi_destroy", "rt_multi_set_bounds", "rt_multi_get_info", "rt_balance_strips",
-                 "rt_suggest_chunks"):
+                 "rt_suggest_chunks", "rt_shared_image_create", "rt_shared_image_open", "rt_shared_image_close",
+                 "rt_shared_image_destroy"):
         getattr(lib, name).restype = i
     _lib = lib
     return lib

@@ -379,6 +379,55 @@ int multi_balance(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_
 
 } // namespace
 
+/* ---- the shared image: the reference's one `pixels` array (src/RayTracer.h:44) for one process per GPU ---- */
+
+static_assert(sizeof(hipIpcMemHandle_t) == RT_SHARED_HANDLE_BYTES, "RT_SHARED_HANDLE_BYTES is the size of a HIP IPC memory handle");
+
+extern "C" int rt_shared_image_create(int device, uint64_t bytes, void **d_image, unsigned char handle[RT_SHARED_HANDLE_BYTES]) {
+    if (!d_image || !handle) return multi_fail(RT_ERR_INVALID, "d_image/handle is NULL");
+    *d_image = nullptr;
+    if (bytes == 0) return multi_fail(RT_ERR_INVALID, "bytes must be positive");
+    HIP_OR_FAIL(hipSetDevice(device));
+    void *p = nullptr;
+    HIP_OR_FAIL(hipMalloc(&p, (size_t)bytes));
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return multi_fail(RT_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e) +
+                                          " (this pool's driver needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment)");
+    }
+    std::memcpy(handle, &h, RT_SHARED_HANDLE_BYTES);
+    *d_image = p;
+    return RT_OK;
+}
+
+extern "C" int rt_shared_image_open(int device, const unsigned char handle[RT_SHARED_HANDLE_BYTES], void **d_image) {
+    if (!d_image || !handle) return multi_fail(RT_ERR_INVALID, "d_image/handle is NULL");
+    *d_image = nullptr;
+    HIP_OR_FAIL(hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, RT_SHARED_HANDLE_BYTES);
+    void *p = nullptr;
+    HIP_OR_FAIL(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *d_image = p;
+    return RT_OK;
+}
+
+extern "C" int rt_shared_image_close(int device, void *d_image) {
+    if (!d_image) return RT_OK;
+    HIP_OR_FAIL(hipSetDevice(device));
+    HIP_OR_FAIL(hipIpcCloseMemHandle(d_image));
+    return RT_OK;
+}
+
+extern "C" int rt_shared_image_destroy(int device, void *d_image) {
+    if (!d_image) return RT_OK;
+    HIP_OR_FAIL(hipSetDevice(device));
+    HIP_OR_FAIL(hipFree(d_image));
+    return RT_OK;
+}
+
 extern "C" int rt_multi_destroy(rt_multi *m) {
     if (!m) return RT_OK;
     for (int g = 0; g < m->ngpu; ++g) {

@@ -303,3 +303,142 @@ class StripPipeline:
         return (f"{self.world} x-strips of " + "/".join(str(b - a) for a, b in self.bounds) + " columns"
                 + (" (measured-cost partition)" if list(self.bounds) != equal_bounds(sum(b - a for a, b in self.bounds), self.world) else "")
                 + (f", each rendered and sent in {self.chunks} column chunks" if self.chunks > 1 else ""))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's ranks all write into ONE `pixels` array while they render (src/RayTracer.h:44; src/RayTracer.cpp:904-923,
+# 1188-1196: the Tilera tiles share that memory) -- there is no gather.  The same for one process per GPU: rank 0 owns the
+# image in its HBM, the other ranks map it (HIP IPC: include/rt_capi.h, rt_shared_image_*) and their kernels store their
+# strips' pixels straight into it over xGMI.
+
+def _collective_device(device):
+    """where the small tensors of control collectives live: the GPU for RCCL, the host for gloo"""
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _everyone(ok, device):
+    """True if `ok` is true on every rank (one small all-reduce)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_collective_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t[0]) == 1
+
+
+class _DeviceMemory:
+    """memory this package allocated through the C ABI, for torch.as_tensor (zero copy)"""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class SharedImage:
+    """One W x H x 3 fp32 image in rank `owner`'s HBM that every rank of the node renders into.
+
+    Collective: every rank constructs it at the same point.  `ptr` is the image's address in THIS process (the owner's
+    allocation, or this rank's mapping of it); column x starts at ptr + x * H * 12.  Raises on every rank, or on none,
+    when the image cannot be shared (no HIP IPC between these processes)."""
+
+    def __init__(self, W, H, device, owner=0):
+        import ctypes as C
+        from . import capi
+        self._capi, self._lib = capi, capi.load_library()
+        self.W, self.H, self.owner, self.rank = int(W), int(H), owner, dist.get_rank()
+        self.device = device
+        self.device_index = device.index if device.index is not None else 0
+        self.ptr, self._mapped = None, False
+        handle = C.create_string_buffer(64)
+        p = C.c_void_p()
+        error = None
+        if self.rank == owner:
+            try:
+                capi.check(self._lib.rt_shared_image_create(self.device_index, self.W * self.H * 12, C.byref(p), handle))
+                self.ptr = p.value
+            except capi.RtError as e:
+                error = str(e)
+        box = [(handle.raw, error)]
+        dist.broadcast_object_list(box, src=owner)
+        raw, error = box[0]
+        if error is None and self.rank != owner:
+            try:
+                capi.check(self._lib.rt_shared_image_open(self.device_index, raw, C.byref(p)))
+                self.ptr, self._mapped = p.value, True
+            except capi.RtError as e:
+                error = str(e)
+        if not _everyone(error is None, device):
+            self.close()
+            raise RuntimeError(f"the image cannot be shared between the ranks: {error or 'another rank could not map it'}")
+
+    def column_ptr(self, x):
+        return self.ptr + int(x) * self.H * 12
+
+    def tensor(self):
+        """The image as a (W, H, 3) torch tensor on this rank's GPU (zero copy)."""
+        return torch.as_tensor(_DeviceMemory(self.ptr, (self.W, self.H, 3)), device=self.device)
+
+    def close(self):
+        """Collective in effect: the owner frees the image after the others have unmapped it (call it on every rank,
+        with a barrier in between if the owner could get here first -- DirectStrips.close() does)."""
+        if self.ptr is None:
+            return
+        if self._mapped:
+            self._lib.rt_shared_image_close(self.device_index, self.ptr)
+        elif self.rank == self.owner:
+            self._lib.rt_shared_image_destroy(self.device_index, self.ptr)
+        self.ptr = None
+
+
+class DirectStrips:
+    """A frame without a gather: every rank's kernel stores its strip straight into the shared image.
+
+    step(): render columns [x0, x1) to image.column_ptr(x0) (`render_ptr(address, x0, x1)` enqueues the kernel on the
+    current stream), then a one-word all-reduce in stream order behind it -- when a rank's all-reduce has completed, every
+    rank's kernel of that frame has, so the frame is whole in the owner's HBM, and the next frame's kernel starts behind it:
+    one frame at a time, with no host synchronisation per frame (RCCL; gloo's collectives run on the host, so there the
+    stream is drained first)."""
+
+    def __init__(self, image, world, rank, device, render_ptr, bounds=None):
+        self.image, self.world, self.rank, self.device, self.render_ptr = image, world, rank, device, render_ptr
+        self.bounds = [tuple(b) for b in (bounds if bounds is not None else equal_bounds(image.W, world))]
+        assert len(self.bounds) == world and self.bounds[0][0] == 0 and self.bounds[-1][1] == image.W
+        assert all(self.bounds[r][1] == self.bounds[r + 1][0] for r in range(world - 1))
+        self.x0, self.x1 = self.bounds[rank]
+        self.strip = max(self.x1 - self.x0, 1)
+        self._host_collectives = dist.get_backend() != "nccl"
+        self._flag = torch.zeros(1, dtype=torch.int32, device=_collective_device(device))
+        self.k = 0
+
+    def step(self):
+        self.k += 1
+        if self.x1 > self.x0:
+            self.render_ptr(self.image.column_ptr(self.x0), self.x0, self.x1)
+        if self._host_collectives:
+            torch.cuda.synchronize(self.device)
+        dist.all_reduce(self._flag)
+
+    def drain(self):
+        pass
+
+    def image_tensor(self):
+        """Rank 0 (the owner): the whole frame."""
+        return self.image.tensor()
+
+    def describe(self):
+        eq = list(self.bounds) == equal_bounds(self.image.W, self.world)
+        return (f"{self.world} x-strips of " + "/".join(str(b - a) for a, b in self.bounds) + " columns"
+                + ("" if eq else " (measured-cost partition)") + ", stored by the kernels straight into rank 0's image (shared over HIP IPC)")
+
+
+def balance_direct(W, my_kernel_ms, device):
+    """Every rank's kernel time on the EQUAL partition (its strip stored into the shared image: a peer's time includes what its
+    link made of the stores) -> (bounds, note): strips of equal measured cost, the same on every rank."""
+    import numpy as np
+    world = dist.get_world_size()
+    mine = torch.tensor([float(my_kernel_ms)], dtype=torch.float64, device=_collective_device(device))
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    kernel_by_rank = [float(t[0]) for t in everyone]
+    cost = np.zeros(W, dtype=np.float64)
+    for (a, b), k in zip(equal_bounds(W, world), kernel_by_rank):
+        if b > a:
+            cost[a:b] = max(k, 0.0) / (b - a)
+    bounds = balanced_bounds(W, world, cost, 0.0)
+    return bounds, f"re-cut after warm-up frames on the equal partition: kernel ms per rank {[round(k, 3) for k in kernel_by_rank]}"
