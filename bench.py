@@ -173,6 +173,14 @@ def parse_args(argv=None):
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1, single-frame mode: column chunks a strip is rendered and sent in (chunk k travels while "
                          "chunk k+1 is rendered); 0 = automatic from the measured kernel and transfer times, 1 = none")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "direct"],
+                    help="N > 1: how the strips reach rank 0.  'rccl': strip buffers + RCCL point-to-point transfers (in column chunks); "
+                         "'direct': rank 0's image is shared over HIP IPC and every rank's kernel stores its strip straight into it "
+                         "(the reference's shared `pixels`); 'auto' times K steps of each and reports the faster as the headline, "
+                         "the other beside it")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the control collectives; gloo is a testing aid (several ranks on one GPU "
+                         "with TCRT_BENCH_ONE_DEVICE=1: RCCL refuses that) and carries the direct transport only")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="N > 1: skip the second, pipelined measurement (gather of frame k under the render of frame k+1)")
     return ap.parse_args(argv)
@@ -466,7 +474,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from tilecoderaytracer_amd import HostScene, Renderer
-    from tilecoderaytracer_amd.distributed import StripPipeline, measure_and_balance
+    from tilecoderaytracer_amd.distributed import DirectStrips, SharedImage, StripPipeline, balance_direct, measure_and_balance
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
@@ -486,11 +494,16 @@ def main(argv=None):
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where the control collectives' small tensors live
+    shared_images = []
 
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def measure(workload, steps, warmup, size=0, overlap=False):
+    def measure(workload, steps, warmup, size=0, overlap=False, transport="rccl"):
         """Warm up, then time exactly `steps` steps of `workload` between two fences
         (barrier + synchronize); returns the MAX over ranks.  overlap=False: every frame is
         rendered and then gathered (one frame's latency); overlap=True: the
@@ -507,7 +520,16 @@ def main(argv=None):
         for kv in args.option:
             k, v = kv.split("=")
             renderer.set_option(k, int(v))
+        direct = transport == "direct"
+        shared = None
+        if direct:                 # rank 0's image, mapped by every other rank (collective: raises on every rank or on none)
+            shared = SharedImage(W, H, dev)
+            shared_images.append(shared)
+
         def make_pipe(bounds=None, chunks=1):
+            if direct:
+                return DirectStrips(shared, world, rank, dev, bounds=bounds,
+                                    render_ptr=lambda address, a, b: renderer.render_device(W, H, depth, a, b, address, stream))
             pp = StripPipeline(W, H, world, rank, dev, render=None, overlap=overlap,
                                force_gather=args.force_dist, bounds=bounds, chunks=chunks, align=16)
             x0_, x1_ = pp.x0, pp.x1
@@ -517,7 +539,7 @@ def main(argv=None):
             return pp
 
         # chunks: given, or decided with the partition below (automatic); one GPU: only if asked for
-        chunks = args.chunks if (args.chunks > 0 and not overlap) else 1
+        chunks = args.chunks if (args.chunks > 0 and not overlap and not direct) else 1
         pipe = make_pipe(chunks=chunks if world == 1 else 1)     # N > 1: the measuring frames run unchunked equal strips
 
         def fence():
@@ -544,13 +566,17 @@ def main(argv=None):
             bounds = None
             agreed_chunks = None
             try:
-                bounds, partition_note, agreed_chunks = measure_and_balance(
-                    pipe, W, my_kernel_ms, fence, dev, overlap=overlap,
-                    chunks=0 if (args.chunks == 0 and not overlap) else chunks)
+                if direct:                   # no transfer to weigh: strips of equal measured kernel time (a peer's includes its link)
+                    bounds, partition_note = balance_direct(W, my_kernel_ms, dev)
+                    agreed_chunks = 1
+                else:
+                    bounds, partition_note, agreed_chunks = measure_and_balance(
+                        pipe, W, my_kernel_ms, fence, dev, overlap=overlap,
+                        chunks=0 if (args.chunks == 0 and not overlap) else chunks)
             except Exception as e:                                         # never lose the run to the tuning step
                 partition_note = f"balanced partition unavailable ({e!r}); equal strips"
             # all ranks take the new strips and chunk count, or none does: `chunks` is the same number on every rank either way
-            ok = torch.tensor([1 if bounds is not None else 0], dtype=torch.int32, device=dev)
+            ok = torch.tensor([1 if bounds is not None else 0], dtype=torch.int32, device=cdev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok[0]) == 1:
                 chunks = agreed_chunks
@@ -590,17 +616,50 @@ def main(argv=None):
         frame_kernel_ms = tm.sum_kernel_ms / max(steps, 1)
         max_frame_kernel_ms = frame_kernel_ms
         if use_dist:
-            t = torch.tensor([elapsed, frame_kernel_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed, frame_kernel_ms], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, max_frame_kernel_ms = float(t[0]), float(t[1])
         return dict(scene_name=scene_name, W=W, H=H, depth=depth, cfg_note=cfg_note, host=host, renderer=renderer,
-                    x0=x0, x1=x1, strip=pipe.strip, pipe=pipe, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=max_frame_kernel_ms,
+                    x0=x0, x1=x1, strip=pipe.strip, pipe=pipe, transport=transport, elapsed=elapsed, kernel_ms=own_kernel_ms, max_kernel_ms=max_frame_kernel_ms,
                     launches_per_frame=launches_per_frame, frame_kernel_ms=frame_kernel_ms,
                     partition=pipe.describe(),
                     partition_note=(partition_note or "") + ("; tile rows of every strip start where rt_learn_tile_order measured best" if learned is True
                                                              else (f"; rt_learn_tile_order {learned}" if learned else "")) or None)
 
-    m = measure(args.workload, args.steps, args.warmup, args.size)
+    def measure_transports(workload, steps, warmup, size=0):
+        """(headline, other, note).  A dist run can deliver the strips to rank 0 in two ways (--transport): `steps` timed steps of
+        each, the faster is the headline and the other is reported beside it.  Every rank takes the same decision: the elapsed
+        times are the all-reduced maxima.  One GPU without --force-dist: one plain measurement."""
+        if not use_dist:
+            return measure(workload, steps, warmup, size), None, None
+        wanted = ["direct"] if args.backend == "gloo" else (["rccl", "direct"] if args.transport == "auto" else [args.transport])
+        done, note = [], None
+        for t in wanted:
+            try:
+                done.append(measure(workload, steps, warmup, size, transport=t))
+            except RuntimeError as e:
+                # the shared image could not be created or mapped: SharedImage raises on every rank, or on none
+                if t == "direct" and len(wanted) > 1 and "cannot be shared" in str(e):
+                    note = f"direct transport unavailable: {e}"
+                    continue
+                raise
+        done.sort(key=lambda r: r["elapsed"])
+        return done[0], (done[1] if len(done) > 1 else None), note
+
+    def transport_words(r):
+        if r["transport"] == "direct":
+            return (" (single frame: every frame is whole in rank 0's HBM before the next starts)")
+        return ", RCCL transfers to rank 0 (single frame: every frame is delivered before the next starts)"
+
+    def other_transport(r, steps):
+        """the transport that did not become the headline, in short"""
+        if r is None:
+            return None
+        return {"transport": r["transport"], "value": round(r["W"] * r["H"] * steps / r["elapsed"] / 1e6, 3), "unit": "Mrays/s",
+                "ms_per_step": round(r["elapsed"] / steps * 1e3, 4), "slowest_rank_frame_kernel_ms": round(r["max_kernel_ms"], 4),
+                "partition": r["partition"] + transport_words(r), "partition_note": r["partition_note"]}
+
+    m, m_other, transport_note = measure_transports(args.workload, args.steps, args.warmup, args.size)
     scene_name, W, H, depth, cfg_note = m["scene_name"], m["W"], m["H"], m["depth"], m["cfg_note"]
     host, renderer, x0, x1, strip = m["host"], m["renderer"], m["x0"], m["x1"], m["strip"]
     elapsed, kernel_ms = m["elapsed"], m["kernel_ms"]
@@ -610,7 +669,7 @@ def main(argv=None):
     grid = None
     if args.workload == "builtin" and not args.size and not args.no_extra:
         g_steps = max(3, args.steps // 5)
-        g = measure("grid32", g_steps, 4 if world > 1 else 2)
+        g, g_other, _ = measure_transports("grid32", g_steps, 4 if world > 1 else 2)
         grid = {
             "workload": f"{g['scene_name']} scene, {g['W']}x{g['H']}, max depth {g['depth']}",
             "baseline_config": g["cfg_note"],
@@ -619,13 +678,17 @@ def main(argv=None):
             "steps": g_steps,
             "ms_per_step": round(g["elapsed"] / g_steps * 1e3, 4),
             "kernel_ms": round(g["kernel_ms"], 4),
-            "partition": g["partition"],
-            "mode": "single frame: render, then gather" if world > 1 else "one launch per frame",
+            "partition": g["partition"] + (transport_words(g) if use_dist else ""),
+            "mode": ("single frame: the kernels store into rank 0's image" if g["transport"] == "direct" else "single frame: render, then gather")
+                    if world > 1 else "one launch per frame",
         }
+        if use_dist:
+            grid["transport"] = g["transport"]
+            grid["other_transport"] = other_transport(g_other, g_steps)
     # N > 1: the throughput of a STREAM of frames (gather of frame k under the render of frame k+1),
     # next to the single-frame headline; a different figure, labelled as such
     pipelined = None
-    if world > 1 and not args.no_pipelined:
+    if world > 1 and not args.no_pipelined and args.backend == "nccl":
         pm = measure(args.workload, args.steps, max(args.warmup, 3), args.size, overlap=True)
         pipelined = {
             "what": "stream of independent frames: RCCL gather of frame k overlapped with the render of frame k+1 "
@@ -681,8 +744,7 @@ def main(argv=None):
                 "workload": f"{scene_name} scene, {W}x{H}, max depth {depth}",
                 "baseline_config": cfg_note,
                 "objects": host.object_count,
-                "partition": m["partition"] + (
-                    ", RCCL transfers to rank 0 (single frame: every frame is delivered before the next starts)" if world > 1 else ""),
+                "partition": m["partition"] + (transport_words(m) if use_dist else ""),
                 "partition_note": m["partition_note"],
                 "block_threads": li.block_threads,
                 "lds_bytes_per_block": li.lds_bytes,
@@ -712,14 +774,20 @@ def main(argv=None):
             # the multi-GPU path's own parity property, measured in this run and outside the timed region: the image the
             # strips were gathered into on rank 0 is, bit for bit, what ONE GPU renders as one frame (dx = x / W uses the
             # global x; the one-GPU frame is what tests/test_parity_gpu.py compares with the oracle)
+            out["config"]["transport"] = m["transport"]
+            out["config"]["other_transport"] = other_transport(m_other, args.steps)
+            if transport_note:
+                out["config"]["transport_note"] = transport_note
             try:
-                gathered = m["pipe"].image(W)
                 whole = torch.empty((W, H, 3), dtype=torch.float32, device=dev)
                 renderer.render_device(W, H, depth, 0, W, whole.data_ptr(), stream)
                 torch.cuda.synchronize(dev)
-                differ = int((gathered[:W].view(torch.int32) != whole.view(torch.int32)).any(dim=2).sum())      # bit patterns
-                out["config"]["gathered_image_vs_one_gpu_frame"] = {
-                    "pixels_compared": W * H, "pixels_differing": differ, "identical": differ == 0}
+                for r, where in ((m, out["config"]), (m_other, out["config"]["other_transport"])):
+                    if r is None:
+                        continue
+                    gathered = r["pipe"].image(W)
+                    differ = int((gathered[:W].view(torch.int32) != whole.view(torch.int32)).any(dim=2).sum())      # bit patterns
+                    where["gathered_image_vs_one_gpu_frame"] = {"pixels_compared": W * H, "pixels_differing": differ, "identical": differ == 0}
                 del whole
             except Exception as e:
                 out["config"]["gathered_image_vs_one_gpu_frame"] = {"error": repr(e)}
@@ -727,7 +795,7 @@ def main(argv=None):
             # what bounds a single frame on N GPUs, in the line itself: every peer's columns cross ONE xGMI link into rank 0
             peer_mb = BYTES_PER_PIXEL * W * H * (world - 1) / world / 1e6
             out["config"]["scaling_note"] = (
-                f"single-frame delivery moves {peer_mb:.0f} MB ({world - 1} strips of 12 B/pixel) into rank 0 per frame, each peer over its own "
+                f"single-frame delivery moves {peer_mb:.0f} MB ({world - 1} strip(s) of 12 B/pixel) into rank 0 per frame, each peer over its own "
                 f"point-to-point xGMI link; frame kernel time of the slowest rank {m['max_kernel_ms']:.3f} ms of {elapsed / args.steps * 1e3:.3f} ms per step: "
                 "where the strips render faster than their columns travel (the built-in scene: 0.6 ms of rendering in all) the figure is "
                 "transfer-bound whatever the partition -- `sphere_grid` is the north star's scaling scene, `pipelined` the throughput "
@@ -779,6 +847,12 @@ def main(argv=None):
 
     if use_dist:
         dist.barrier()
+        for image in shared_images:              # the mappings first, then rank 0's allocations
+            if rank != 0:
+                image.close()
+        dist.barrier()
+        for image in shared_images:
+            image.close()
         dist.destroy_process_group()
 
 

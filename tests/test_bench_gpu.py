@@ -46,7 +46,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 def test_bench_force_dist_runs_the_chunked_single_frame_path_on_one_gpu():
     """--force-dist: torch.distributed over RCCL with one rank; --chunks 4: every frame in four column-chunk launches."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--force-dist", "--chunks", "4",
-                          "--no-cpu-baseline", "--no-extra", "--workload", "grid16d8", "--size", "512"],
+                          "--transport", "rccl", "--no-cpu-baseline", "--no-extra", "--workload", "grid16d8", "--size", "512"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -55,6 +55,7 @@ def test_bench_force_dist_runs_the_chunked_single_frame_path_on_one_gpu():
     assert "4 column chunks" in j["config"]["partition"] and j["value"] > 10.0
     # what the chunks were gathered into is the frame one launch renders, bit for bit (bench.py measures that itself on a dist run)
     assert j["config"]["gathered_image_vs_one_gpu_frame"] == {"pixels_compared": 512 * 512, "pixels_differing": 0, "identical": True}
+    assert j["config"]["transport"] == "rccl" and j["config"]["other_transport"] is None
     r = j["roofline"]
     assert r["kernel"].startswith("rt_render_kernel_clusters")
     # four launches per frame: a launch's share of the pixels over a launch's average duration, which is the frame's
@@ -77,3 +78,47 @@ def test_bench_shipped_workload_times_the_executable_end_to_end():
     assert j["config"]["pixel_lines_md5"] == "ee680aed641062c6f3a5e0b3fba94199"       # the reference's 512x512 d3 text body
     assert j["config"]["identical_to_cpu_oracle_output"] is True
     assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["us_per_pixel"] > 0 and j["config"]["us_per_pixel"] > 0
+
+
+SAME = {"pixels_compared": 512 * 512, "pixels_differing": 0, "identical": True}
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_times_both_transports_on_one_gpu():
+    """--force-dist with the default --transport auto: K steps through the strip buffer + RCCL, K steps with the kernel storing
+    into the shared image; the faster is the headline, the other is beside it, and both images equal one GPU's frame."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--force-dist",
+                          "--no-cpu-baseline", "--no-extra", "--workload", "grid16d8", "--size", "512"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    c = json.loads(lines[0])["config"]
+    assert {c["transport"], c["other_transport"]["transport"]} == {"rccl", "direct"}
+    assert c["gathered_image_vs_one_gpu_frame"] == SAME and c["other_transport"]["gathered_image_vs_one_gpu_frame"] == SAME
+    assert c["other_transport"]["value"] > 10.0 and "transport_note" not in c
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_store_into_the_shared_image():
+    """`bench.py --gpus 2` starts its own two ranks; TCRT_BENCH_ONE_DEVICE puts both on the box's one GPU and --backend gloo
+    carries the control collectives (RCCL refuses two ranks on one device): the whole N > 1 sequence -- equal strips, every rank's
+    kernel time, the re-cut, rt_learn_tile_order per strip, K timed frames -- with the direct transport,
+    and rank 0's image compared with one GPU's frame."""
+    env = dict(os.environ, TCRT_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3",
+                          "--backend", "gloo", "--size", "512"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 10.0
+    assert c["transport"] == "direct" and c["other_transport"] is None
+    assert c["gathered_image_vs_one_gpu_frame"] == SAME
+    assert "2 x-strips of" in c["partition"] and "straight into rank 0's image" in c["partition"]
+    assert "kernel ms per rank" in c["partition_note"] and "rt_learn_tile_order" in c["partition_note"]
+    assert "MB" in c["scaling_note"] and "cpu_baseline" not in j

@@ -48,7 +48,7 @@ def _direct_worker(rank, world, scene_name, W, H, depth, bounds, frames, init_fi
         pipe.step()
     # step() returns when every rank's kernel of the frame has completed: rank 0 may read the image now
     if rank == 0:
-        np.save(out_file, pipe.image_tensor().cpu().numpy())
+        np.save(out_file, pipe.image(W).cpu().numpy())
         assert "straight into rank 0's image" in pipe.describe()
     dist.barrier()
     if rank != 0:

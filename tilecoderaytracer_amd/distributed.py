@@ -395,10 +395,10 @@ class DirectStrips:
     one frame at a time, with no host synchronisation per frame (RCCL; gloo's collectives run on the host, so there the
     stream is drained first)."""
 
-    def __init__(self, image, world, rank, device, render_ptr, bounds=None):
-        self.image, self.world, self.rank, self.device, self.render_ptr = image, world, rank, device, render_ptr
-        self.bounds = [tuple(b) for b in (bounds if bounds is not None else equal_bounds(image.W, world))]
-        assert len(self.bounds) == world and self.bounds[0][0] == 0 and self.bounds[-1][1] == image.W
+    def __init__(self, shared, world, rank, device, render_ptr, bounds=None):
+        self.shared, self.world, self.rank, self.device, self.render_ptr = shared, world, rank, device, render_ptr
+        self.bounds = [tuple(b) for b in (bounds if bounds is not None else equal_bounds(shared.W, world))]
+        assert len(self.bounds) == world and self.bounds[0][0] == 0 and self.bounds[-1][1] == shared.W
         assert all(self.bounds[r][1] == self.bounds[r + 1][0] for r in range(world - 1))
         self.x0, self.x1 = self.bounds[rank]
         self.strip = max(self.x1 - self.x0, 1)
@@ -409,7 +409,7 @@ class DirectStrips:
     def step(self):
         self.k += 1
         if self.x1 > self.x0:
-            self.render_ptr(self.image.column_ptr(self.x0), self.x0, self.x1)
+            self.render_ptr(self.shared.column_ptr(self.x0), self.x0, self.x1)
         if self._host_collectives:
             torch.cuda.synchronize(self.device)
         dist.all_reduce(self._flag)
@@ -417,12 +417,12 @@ class DirectStrips:
     def drain(self):
         pass
 
-    def image_tensor(self):
-        """Rank 0 (the owner): the whole frame."""
-        return self.image.tensor()
+    def image(self, W=None):
+        """Rank 0 (the owner): the whole frame, as StripPipeline.image() gives it; None elsewhere."""
+        return self.shared.tensor() if self.rank == self.shared.owner else None
 
     def describe(self):
-        eq = list(self.bounds) == equal_bounds(self.image.W, self.world)
+        eq = list(self.bounds) == equal_bounds(self.shared.W, self.world)
         return (f"{self.world} x-strips of " + "/".join(str(b - a) for a, b in self.bounds) + " columns"
                 + ("" if eq else " (measured-cost partition)") + ", stored by the kernels straight into rank 0's image (shared over HIP IPC)")
 
