@@ -35,7 +35,8 @@ extern "C" {
 
 #define RT_CAPI_VERSION 4      /* 3: strips cut by measured cost (rt_multi_render chunks = 0, rt_balance_strips, rt_suggest_chunks,
                                 * rt_multi_set_bounds, rt_multi_get_info); options, counters and calibration moved to rt_capi_tuning.h
-                                * 4: rt_shared_image_* (one image in one GPU's HBM that the other GPUs' processes render into) */
+                                * 4: rt_shared_image_* (one image in one GPU's HBM that the other GPUs' processes render into); rt_multi_render measures
+                                *    a direct-store transport beside RCCL (rt_multi_info.transport, .trial_frame_ms) */
 
 enum {
     RT_OK = 0,
@@ -156,18 +157,26 @@ int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W,
  *                   nothing, renders as long as a peer needs to render and ship its columns
  *                   (rt_balance_strips), with rt_suggest_chunks's chunk count; later calls of the same
  *                   shape reuse the cut.  The image is the same for every partition.
+ *                   Where every GPU may address device 0's memory (peer access over xGMI) the same call also measures
+ *                   the DIRECT transport -- every GPU's kernel stores its strip straight into the image on device 0,
+ *                   as the reference's ranks write into the one `pixels` array; no strip buffer, no transfer, strips of
+ *                   equal measured kernel time -- renders one frame of each transport on its own cut and keeps the
+ *                   faster (rt_multi_info.transport, .trial_frame_ms).
  * A failed frame leaves nothing queued on any GPU and no RCCL group open; after a failed RCCL call
  * the handle refuses further frames (RT_ERR_RCCL): destroy it. */
 #define RT_MULTI_MAX_GPUS 16
 typedef struct rt_multi rt_multi;
+enum { RT_MULTI_TRANSPORT_AUTO = 0, RT_MULTI_TRANSPORT_RCCL = 1, RT_MULTI_TRANSPORT_DIRECT = 2 };
 typedef struct rt_multi_info {                      /* of the last rt_multi_render */
     int32_t ngpu, chunks;
     int32_t balanced;                               /* 1: the strips were cut by measured cost */
+    int32_t transport;                              /* RT_MULTI_TRANSPORT_RCCL: strip buffers + ncclSend / ncclRecv; _DIRECT: the kernels stored into device 0's image */
     int32_t bounds[RT_MULTI_MAX_GPUS + 1];          /* GPU g rendered columns [bounds[g], bounds[g + 1]) */
     double  kernel_ms[RT_MULTI_MAX_GPUS];           /* per GPU: its kernels of that frame (HIP events) */
     double  frame_ms;                               /* host clock: first enqueue until everything was on device 0 */
     double  measured_kernel_ms[RT_MULTI_MAX_GPUS];  /* what the cut was computed from: every GPU's equal strip ... */
     double  measured_gather_ms;                     /* ... and the equal strips' transfers on their own */
+    double  trial_frame_ms[2];                      /* the automatic choice of transport: one frame of each on its own cut, [0] RCCL, [1] direct (0: not tried) */
 } rt_multi_info;
 int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **out);
 int rt_multi_render(rt_multi *multi, const rt_camera_desc *cam, int W, int H, int max_depth,

@@ -154,7 +154,9 @@ int rt_get_launch_info(const rt_scene *scene, rt_launch_info *out);
  *                   spheres, 20 below 896, 24 below 3 000, else 32; 0 = no clustering) */
 int rt_set_option(rt_scene *scene, const char *key, int value);
 
-int rt_multi_set_option(rt_multi *multi, const char *key, int value);   /* rt_set_option on every GPU's scene */
+/* rt_set_option on every GPU's scene -- and the handle's own option "transport": RT_MULTI_TRANSPORT_AUTO (0, the default: measured,
+ * include/rt_capi.h at rt_multi_render), _RCCL (1) or _DIRECT (2: refused unless every GPU has peer access to device 0) */
+int rt_multi_set_option(rt_multi *multi, const char *key, int value);
 
 int rt_capi_tuning_version(void);
 

@@ -501,6 +501,66 @@ def test_multi_handle_automatic_partition_and_callers_bounds(oracle):
         assert_same(out, orc.render(W, H, depth), "after two failed frames")
         capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 4, out.ctypes.data))
         assert_same(out, orc.render(W, H, depth), "after two failed frames, chunked")
+        # the handle's own option: how the strips reach device 0 (with one GPU there is nothing to carry: the setting is
+        # accepted, re-measures, and changes no pixel; rt_multi_info says RCCL, the transport of a handle without peers)
+        capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+        assert info.transport == 1 and info.trial_frame_ms[0] == 0.0 and info.trial_frame_ms[1] == 0.0
+        for transport in (2, 1, 0):
+            capi.check(lib.rt_multi_set_option(m, b"transport", transport))
+            out[:] = 0
+            capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+            assert_same(out, orc.render(W, H, depth), f"transport {transport}")
+            capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+            assert info.transport == 1 and info.chunks == 1
+        assert lib.rt_multi_set_option(m, b"transport", 3) == capi.RT_ERR_INVALID and b"transport" in lib.rt_last_error()
+        assert lib.rt_multi_set_option(m, b"transport", -1) == capi.RT_ERR_INVALID
+    finally:
+        capi.check(lib.rt_multi_destroy(m))
+
+
+@pytest.mark.parametrize("ngpu", [2, 3])
+def test_multi_handle_direct_stores_several_strips_on_one_device(oracle, monkeypatch, ngpu):
+    """The DIRECT transport of the one-process multi-GPU path -- every GPU's kernel stores its strip straight into the image on
+    device 0 -- with ngpu strips, scenes, streams and the measured cut, all on the box's one device (TCRT_MULTI_ONE_DEVICE=1, a
+    testing aid read by rt_multi_create: no RCCL, which refuses two ranks on a device).  Peer access itself needs two GPUs."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    lib = capi.load_library()
+    monkeypatch.setenv("TCRT_MULTI_ONE_DEVICE", "1")
+    host, orc = HostScene.named("grid16"), oracle.OracleScene.named("grid16")
+    W, H, depth = 200, 96, 6
+    want = orc.render(W, H, depth)
+    m = C.c_void_p()
+    capi.check(lib.rt_multi_create(host.desc, ngpu, C.byref(m)))
+    try:
+        info = capi.RtMultiInfo()
+        for _ in range(2):                                    # the second frame reuses the measured cut
+            out = np.zeros((W, H, 3), dtype=np.float32)
+            capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+            assert_same(out, want, f"{ngpu} strips, direct stores, measured cut")
+            capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+            assert info.ngpu == ngpu and info.transport == 2 and info.balanced == 1 and info.chunks == 1
+            assert info.bounds[0] == 0 and info.bounds[ngpu] == W and all(info.bounds[g] <= info.bounds[g + 1] for g in range(ngpu))
+            assert all(info.measured_kernel_ms[g] > 0.0 for g in range(ngpu)) and info.measured_gather_ms == 0.0
+            assert info.trial_frame_ms[0] == 0.0 and info.trial_frame_ms[1] == 0.0      # nothing to choose between: no RCCL here
+            assert all(info.kernel_ms[g] > 0.0 for g in range(ngpu) if info.bounds[g + 1] > info.bounds[g])
+        # the caller's own strips (one of them empty, none on a tile boundary) and an explicit chunk count: still direct stores
+        cut = [0, 37, 37, W] if ngpu == 3 else [0, 123, W]
+        capi.check(lib.rt_multi_set_bounds(m, W, (C.c_int * (ngpu + 1))(*cut), 4))
+        out = np.zeros((W, H, 3), dtype=np.float32)
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+        assert_same(out, want, "caller's strips")
+        capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+        assert [info.bounds[g] for g in range(ngpu + 1)] == cut and info.transport == 2 and info.chunks == 1
+        capi.check(lib.rt_multi_set_bounds(m, 0, None, 0))
+        out[:] = 0
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 3, out.ctypes.data))       # equal strips
+        assert_same(out, want, "equal strips")
+        assert lib.rt_multi_set_option(m, b"transport", 1) == capi.RT_ERR_INVALID and b"RCCL" in lib.rt_last_error()
+        capi.check(lib.rt_multi_set_option(m, b"transport", 2))
+        out[:] = 0
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+        assert_same(out, want, "transport 2")
     finally:
         capi.check(lib.rt_multi_destroy(m))
 
@@ -518,6 +578,24 @@ def test_host_executable_writes_the_reference_log(oracle, tmp_path):
     got_lines = out.read_bytes().split(b"\n")
     want_lines = want.read_bytes().split(b"\n")
     assert got_lines[:7] == want_lines[:7] and got_lines[9:] == want_lines[9:]   # only the two timing lines vary
+
+
+def test_host_executable_with_three_strips_on_one_device(oracle, tmp_path):
+    """tcrt_raytracer --gpus 3 (the reference's CORE_NUM) with TCRT_MULTI_ONE_DEVICE=1: three strips cut by measured cost, stored
+    by their kernels straight into GPU 0's image; the pixel lines are those of the one-GPU run, the log names the partition."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "tilecoderaytracer_amd", "bin", "tcrt_raytracer")
+    out = tmp_path / "raytracer_screen.txt"
+    run = subprocess.run([exe, "--width", "150", "--height", "64", "--depth", "5", "--gpus", "3", "--out", str(out)], check=True,
+                         stdout=subprocess.PIPE, cwd=tmp_path, env=dict(os.environ, TCRT_MULTI_ONE_DEVICE="1"))
+    text = run.stdout.decode()
+    assert "Partition: 3 x-strips of" in text and "cut by measured cost" in text and "straight into GPU 0's image" in text
+    want = tmp_path / "want.txt"
+    oracle.write_screen_txt(str(want), oracle.OracleScene.builtin().render(150, 64, 5), 0.0, 0.0)
+    got_lines, want_lines = out.read_bytes().split(b"\n"), want.read_bytes().split(b"\n")
+    got_pixels, want_pixels = [l for l in got_lines if l[:1] == b"("], [l for l in want_lines if l[:1] == b"("]
+    assert len(want_pixels) == 150 * 64 and got_pixels == want_pixels
+    assert b"Number_of_Cores:3." in got_lines
 
 
 # ------------------------------------------------ stress for the exact culls

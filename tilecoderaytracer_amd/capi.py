@@ -72,12 +72,13 @@ RT_MULTI_MAX_GPUS = 16
 
 class RtMultiInfo(C.Structure):
     _fields_ = [
-        ("ngpu", C.c_int32), ("chunks", C.c_int32), ("balanced", C.c_int32),
+        ("ngpu", C.c_int32), ("chunks", C.c_int32), ("balanced", C.c_int32), ("transport", C.c_int32),
         ("bounds", C.c_int32 * (RT_MULTI_MAX_GPUS + 1)),
         ("kernel_ms", C.c_double * RT_MULTI_MAX_GPUS),
         ("frame_ms", C.c_double),
         ("measured_kernel_ms", C.c_double * RT_MULTI_MAX_GPUS),
         ("measured_gather_ms", C.c_double),
+        ("trial_frame_ms", C.c_double * 2),
     ]
 
 

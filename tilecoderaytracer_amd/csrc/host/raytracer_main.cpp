@@ -115,8 +115,12 @@ int main(int argc, char **argv) {
                 std::printf("%s%d", g ? "/" : " ", info.bounds[g + 1] - info.bounds[g]);
                 if (info.kernel_ms[g] > kernel_ms) kernel_ms = info.kernel_ms[g];
             }
-            std::printf(" columns (%s), %d column chunk(s) per strip; frame %f ms\n",
-                        info.balanced ? "cut by measured cost" : "equal", info.chunks, info.frame_ms);
+            if (info.transport == RT_MULTI_TRANSPORT_DIRECT)
+                std::printf(" columns (%s), stored by the kernels straight into GPU 0's image; frame %f ms\n",
+                            info.balanced ? "cut by measured cost" : "equal", info.frame_ms);
+            else
+                std::printf(" columns (%s), %d column chunk(s) per strip; frame %f ms\n",
+                            info.balanced ? "cut by measured cost" : "equal", info.chunks, info.frame_ms);
         }
         rt_multi_destroy(multi);
     }

@@ -38,6 +38,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -190,6 +191,16 @@ struct rt_multi {
     int key[3] = {0, 0, 0};                          /* W, H, max_depth */
     rt_camera_desc key_cam{};
     bool broken = false;                             /* an RCCL call failed mid-frame: the communicator's state is unknown */
+    /* DIRECT: every GPU's kernel stores its strip straight into the image on device 0 (peer access over xGMI) -- the reference's
+     * ranks writing into the one `pixels` array, src/RayTracer.cpp:904-923, 1188-1196; no strip buffer, no transfer.  Possible
+     * when every GPU may address device 0's memory; whether it is FASTER than strip buffers + RCCL is measured (multi_balance). */
+    std::vector<int> dev;                            /* HIP device of GPU g of this handle: g -- or 0 for all of them under the testing aid
+                                                      * TCRT_MULTI_ONE_DEVICE=1 (a box with one GPU: the strips' arithmetic, the direct stores
+                                                      * and the measurement run as for ngpu GPUs, on one device; no RCCL, which refuses that) */
+    bool have_rccl = false;                          /* strip buffers + ncclSend / ncclRecv are available */
+    bool peer_ok = false;                            /* every GPU g >= 1 may store into device 0's memory */
+    int transport_wanted = RT_MULTI_TRANSPORT_AUTO;  /* rt_multi_set_option("transport") */
+    bool direct = false;                             /* the transport of the partition in use */
     rt_multi_info info{};
 };
 
@@ -208,7 +219,7 @@ void strip_of(const rt_multi *m, int W, int g, int *x0, int *x1) {
 /* after a failure somewhere in a frame: nothing of it may still be queued when the caller gets the handle back */
 void drain_all(rt_multi *m) {
     for (int g = 0; g < m->ngpu; ++g) {
-        if (hipSetDevice(g) != hipSuccess) continue;
+        if (hipSetDevice(m->dev[(size_t)g]) != hipSuccess) continue;
         if (m->compute[(size_t)g]) (void)hipStreamSynchronize(m->compute[(size_t)g]);
         if (m->comm[(size_t)g]) (void)hipStreamSynchronize(m->comm[(size_t)g]);
     }
@@ -218,8 +229,11 @@ void drain_all(rt_multi *m) {
  * and -- transfers -- chunk k goes to device 0 behind its kernel while chunk k + 1 is rendered; returns when everything is on
  * device 0.  render = false: the transfers alone (the strips' columns as they are).  Any failure leaves no work queued and
  * no RCCL group open. */
-int multi_frame(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_depth, int chunks, bool render, bool transfers) {
+int multi_frame(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_depth, int chunks, bool render, bool transfers,
+                bool direct = false) {
     const int ngpu = m->ngpu;
+    if (direct) transfers = false;                   /* the pixels are where they belong when the kernels are done */
+    if (ngpu > 1 && transfers && !m->have_rccl) return multi_fail(RT_ERR_RCCL, "this handle has no RCCL communicator");
     const size_t column_floats = (size_t)H * 3;
     bool group_open = false;
     auto body = [&]() -> int {
@@ -238,12 +252,12 @@ int multi_frame(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_de
                 int x0 = 0, x1 = 0, a = 0, b = 0;
                 strip_of(m, W, g, &x0, &x1);
                 (void)rt_chunk_bounds(x0, x1, chunks, k, kAlign, &a, &b);
-                float *dst = g == 0 ? static_cast<float *>(m->d_full) + (size_t)a * column_floats
-                                    : static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats;
+                float *dst = (g == 0 || direct) ? static_cast<float *>(m->d_full) + (size_t)a * column_floats
+                                                : static_cast<float *>(m->d_strip[(size_t)g]) + (size_t)(a - x0) * column_floats;
                 int rc = rt_render_device(m->scenes[(size_t)g], cam, W, H, a, b, max_depth, dst, m->compute[(size_t)g]);
                 if (rc) return rc;
                 if (g == 0 || !transfers) continue;           /* device 0 sends nothing: its receipts wait for no kernel of its own */
-                HIP_STEP(hipSetDevice(g));
+                HIP_STEP(hipSetDevice(m->dev[(size_t)g]));
                 HIP_STEP(hipEventRecord(m->rendered[(size_t)g][(size_t)k], m->compute[(size_t)g]));
                 HIP_STEP(hipStreamWaitEvent(m->comm[(size_t)g], m->rendered[(size_t)g][(size_t)k], 0));
             }
@@ -266,7 +280,7 @@ int multi_frame(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_de
             }
         }
         for (int g = 0; g < ngpu; ++g) {
-            HIP_STEP(hipSetDevice(g));
+            HIP_STEP(hipSetDevice(m->dev[(size_t)g]));
             HIP_STEP(hipStreamSynchronize(m->compute[(size_t)g]));
             HIP_STEP(hipStreamSynchronize(m->comm[(size_t)g]));
         }
@@ -294,14 +308,14 @@ int multi_frame(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_de
 int multi_reserve(rt_multi *m, int W, int H, int chunks) {
     const size_t column_floats = (size_t)H * 3;
     const size_t image_bytes = (size_t)W * column_floats * sizeof(float);
-    HIP_OR_FAIL(hipSetDevice(0));
+    HIP_OR_FAIL(hipSetDevice(m->dev[0]));
     if (image_bytes > m->full_bytes) {
         if (m->d_full) { HIP_OR_FAIL(hipFree(m->d_full)); m->d_full = nullptr; m->full_bytes = 0; }
         HIP_OR_FAIL(hipMalloc(&m->d_full, image_bytes));
         m->full_bytes = image_bytes;
     }
     for (int g = 0; g < m->ngpu; ++g) {
-        HIP_OR_FAIL(hipSetDevice(g));
+        HIP_OR_FAIL(hipSetDevice(m->dev[(size_t)g]));
         int x0 = 0, x1 = 0;
         strip_of(m, W, g, &x0, &x1);
         const size_t need = (size_t)std::max(x1 - x0, 1) * column_floats * sizeof(float);
@@ -339,10 +353,14 @@ int multi_balance(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_
     double gather_ms = 0.0;
     int chunks = 1;
     std::vector<int> cut = equal;
+    const bool try_rccl = ngpu > 1 && m->have_rccl && m->transport_wanted != RT_MULTI_TRANSPORT_DIRECT;
+    const bool try_direct = ngpu > 1 && m->peer_ok && (m->transport_wanted != RT_MULTI_TRANSPORT_RCCL || !m->have_rccl);
     if (ngpu > 1) {
         int rc = multi_reserve(m, W, H, 1);
         if (rc) return rc;
-        rc = multi_frame(m, cam, W, H, max_depth, 1, true, true);
+    }
+    if (try_rccl) {
+        int rc = multi_frame(m, cam, W, H, max_depth, 1, true, true);
         if (rc) return rc;
         for (int g = 0; g < ngpu; ++g) { rc = rt_reset_timing(m->scenes[(size_t)g]); if (rc) return rc; }
         rc = multi_frame(m, cam, W, H, max_depth, 1, true, false);
@@ -364,6 +382,52 @@ int multi_balance(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_
         const double per_column = gather_ms / (double)std::max(equal[1] - equal[0], 1);
         if (rt_balance_strips(W, ngpu, equal.data(), kernel_ms.data(), per_column, chunks, cut.data()))
             return multi_fail(RT_ERR_INVALID, "rt_balance_strips refused the measured times");
+    }
+    /* DIRECT (see struct rt_multi): the same measurement without transfers -- every GPU's kernel time with its equal strip stored
+     * into device 0's image (a peer's includes what its link made of the stores), strips of equal measured time -- and then one
+     * whole frame of each transport on its own cut, by the host clock: the faster one is kept.  "transport" 1 / 2 skip the trial. */
+    m->direct = false;
+    m->info.transport = RT_MULTI_TRANSPORT_RCCL;
+    m->info.trial_frame_ms[0] = m->info.trial_frame_ms[1] = 0.0;
+    if (try_direct) {
+        std::vector<double> direct_ms((size_t)ngpu, 0.0);
+        std::vector<int> direct_cut = equal;
+        int rc = multi_frame(m, cam, W, H, max_depth, 1, true, false, true);          /* first touch of the peer mappings */
+        if (rc) return rc;
+        for (int g = 0; g < ngpu; ++g) { rc = rt_reset_timing(m->scenes[(size_t)g]); if (rc) return rc; }
+        rc = multi_frame(m, cam, W, H, max_depth, 1, true, false, true);
+        if (rc) return rc;
+        for (int g = 0; g < ngpu; ++g) {
+            rt_timing tm;
+            rc = rt_get_timing(m->scenes[(size_t)g], &tm);
+            if (rc) return rc;
+            direct_ms[(size_t)g] = tm.sum_kernel_ms;
+        }
+        if (rt_balance_strips(W, ngpu, equal.data(), direct_ms.data(), 0.0, 1, direct_cut.data()))
+            return multi_fail(RT_ERR_INVALID, "rt_balance_strips refused the measured times");
+        bool use_direct = !try_rccl;
+        if (try_rccl) {                                  /* both are possible and neither was asked for: one frame of each */
+            m->bounds = cut; m->bounds_W = W;
+            rc = multi_reserve(m, W, H, chunks);
+            if (rc) return rc;
+            double t0 = now_ms();
+            rc = multi_frame(m, cam, W, H, max_depth, chunks, true, true);
+            if (rc) return rc;
+            m->info.trial_frame_ms[0] = now_ms() - t0;
+            m->bounds = direct_cut;
+            t0 = now_ms();
+            rc = multi_frame(m, cam, W, H, max_depth, 1, true, false, true);
+            if (rc) return rc;
+            m->info.trial_frame_ms[1] = now_ms() - t0;
+            use_direct = m->info.trial_frame_ms[1] < m->info.trial_frame_ms[0];
+        }
+        if (use_direct) {
+            cut = direct_cut;
+            chunks = 1;
+            kernel_ms = direct_ms;
+            m->direct = true;
+            m->info.transport = RT_MULTI_TRANSPORT_DIRECT;
+        }
     }
     m->bounds = cut;
     m->bounds_W = W;
@@ -431,7 +495,7 @@ extern "C" int rt_shared_image_destroy(int device, void *d_image) {
 extern "C" int rt_multi_destroy(rt_multi *m) {
     if (!m) return RT_OK;
     for (int g = 0; g < m->ngpu; ++g) {
-        (void)hipSetDevice(g);
+        (void)hipSetDevice((size_t)g < m->dev.size() ? m->dev[(size_t)g] : g);
         if ((size_t)g < m->comms.size() && m->comms[(size_t)g] && m->rccl.CommDestroy) m->rccl.CommDestroy(m->comms[(size_t)g]);
         if ((size_t)g < m->rendered.size())
             for (hipEvent_t e : m->rendered[(size_t)g]) (void)hipEventDestroy(e);
@@ -440,7 +504,7 @@ extern "C" int rt_multi_destroy(rt_multi *m) {
         if ((size_t)g < m->d_strip.size() && m->d_strip[(size_t)g]) (void)hipFree(m->d_strip[(size_t)g]);
         if ((size_t)g < m->scenes.size() && m->scenes[(size_t)g]) rt_scene_destroy(m->scenes[(size_t)g]);
     }
-    if (m->d_full) { (void)hipSetDevice(0); (void)hipFree(m->d_full); }
+    if (m->d_full) { (void)hipSetDevice(m->dev.empty() ? 0 : m->dev[0]); (void)hipFree(m->d_full); }
     if (m->rccl.handle) dlclose(m->rccl.handle);
     delete m;
     return RT_OK;
@@ -454,10 +518,14 @@ extern "C" int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **o
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return multi_fail(RT_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
-    if (ngpu > ndev) return multi_fail(RT_ERR_INVALID, "ngpu exceeds the visible devices");
+    const char *one = std::getenv("TCRT_MULTI_ONE_DEVICE");
+    const bool one_device = one && one[0] == '1';
+    if (ngpu > ndev && !one_device) return multi_fail(RT_ERR_INVALID, "ngpu exceeds the visible devices");
     rt_multi *m = new (std::nothrow) rt_multi();
     if (!m) return multi_fail(RT_ERR_INVALID, "out of memory");
     m->ngpu = ngpu;
+    m->dev.assign((size_t)ngpu, 0);
+    for (int g = 0; g < ngpu && !one_device; ++g) m->dev[(size_t)g] = g;
     m->scenes.assign((size_t)ngpu, nullptr);
     m->compute.assign((size_t)ngpu, nullptr);
     m->comm.assign((size_t)ngpu, nullptr);
@@ -468,20 +536,33 @@ extern "C" int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **o
     m->info.ngpu = ngpu;
     auto bail = [&](int rc) { rt_multi_destroy(m); return rc; };
     for (int g = 0; g < ngpu; ++g) {
-        int rc = rt_scene_create(desc, g, &m->scenes[(size_t)g]);
+        int rc = rt_scene_create(desc, m->dev[(size_t)g], &m->scenes[(size_t)g]);
         if (rc) return bail(rc);
-        hipError_t e = hipSetDevice(g);
+        hipError_t e = hipSetDevice(m->dev[(size_t)g]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->compute[(size_t)g], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->comm[(size_t)g], hipStreamNonBlocking);
         if (e != hipSuccess) return bail(multi_fail(RT_ERR_HIP, std::string("stream setup: ") + hipGetErrorString(e)));
     }
-    if (ngpu > 1) {
+    m->peer_ok = ngpu > 1;
+    for (int g = 1; g < ngpu && !one_device; ++g) {     /* may GPU g's kernels store into device 0's memory? */
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g, 0) != hipSuccess || !can) { m->peer_ok = false; break; }
+        hipError_t e = hipSetDevice(g);
+        if (e == hipSuccess) e = hipDeviceEnablePeerAccess(0, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+        if (e != hipSuccess) { (void)hipGetLastError(); m->peer_ok = false; break; }
+    }
+    if (ngpu > 1 && !one_device) {
+        /* RCCL: needed where a GPU cannot address device 0's memory; with peer access everywhere its absence leaves the direct stores */
         std::string err;
-        if (!load_rccl(m->rccl, err)) return bail(multi_fail(RT_ERR_RCCL, err));
-        std::vector<int> devs((size_t)ngpu);
-        for (int g = 0; g < ngpu; ++g) devs[(size_t)g] = g;
-        ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), ngpu, devs.data());
-        if (r != 0) return bail(multi_fail(RT_ERR_RCCL, std::string("ncclCommInitAll: ") + m->rccl.GetErrorString(r)));
+        if (load_rccl(m->rccl, err)) {
+            std::vector<int> devs((size_t)ngpu);
+            for (int g = 0; g < ngpu; ++g) devs[(size_t)g] = g;
+            ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), ngpu, devs.data());
+            if (r == 0) m->have_rccl = true;
+            else err = std::string("ncclCommInitAll: ") + m->rccl.GetErrorString(r);
+        }
+        if (!m->have_rccl && !m->peer_ok) return bail(multi_fail(RT_ERR_RCCL, err));
     }
     *out = m;
     return RT_OK;
@@ -489,6 +570,17 @@ extern "C" int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **o
 
 extern "C" int rt_multi_set_option(rt_multi *m, const char *key, int value) {
     if (!m) return multi_fail(RT_ERR_INVALID, "handle is NULL");
+    if (key && std::strcmp(key, "transport") == 0) {           /* the handle's own option: how the strips reach device 0 */
+        if (value < RT_MULTI_TRANSPORT_AUTO || value > RT_MULTI_TRANSPORT_DIRECT)
+            return multi_fail(RT_ERR_INVALID, "transport: 0 automatic (measured), 1 strip buffers + RCCL, 2 direct stores into device 0's image");
+        if (value == RT_MULTI_TRANSPORT_DIRECT && m->ngpu > 1 && !m->peer_ok)
+            return multi_fail(RT_ERR_INVALID, "transport 2: not every GPU of this handle has peer access to device 0");
+        if (value == RT_MULTI_TRANSPORT_RCCL && m->ngpu > 1 && !m->have_rccl)
+            return multi_fail(RT_ERR_INVALID, "transport 1: this handle has no RCCL communicator");
+        m->transport_wanted = value;
+        m->have_key = false;                                     /* the next automatic frame measures again */
+        return RT_OK;
+    }
     for (rt_scene *s : m->scenes) {
         int rc = rt_set_option(s, key, value);
         if (rc) return rc;
@@ -530,6 +622,8 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_camera_desc *cam, int W, in
     if (m->broken)
         return multi_fail(RT_ERR_RCCL, "an RCCL call failed in an earlier frame of this handle: destroy it and create another");
     const int ngpu = m->ngpu;
+    /* the caller's own strips or chunk count: the transport is the one asked for ("transport" 2: direct stores), else RCCL */
+    bool direct = ngpu > 1 && m->peer_ok && (m->transport_wanted == RT_MULTI_TRANSPORT_DIRECT || !m->have_rccl);
     if (chunks == 0) {
         /* automatic: the strips of rt_multi_set_bounds if there are any, else the measured-cost partition for this shape */
         if (m->bounds_explicit && m->bounds_W == W) {
@@ -542,22 +636,26 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_camera_desc *cam, int W, in
                 if (rc) return rc;
             }
             chunks = m->bounds_chunks;
+            direct = m->direct;                          /* what the measurement chose */
         }
     } else if (!m->bounds_explicit && !m->bounds.empty()) {
         m->bounds.clear();                               /* an explicit chunk count on a measured partition: equal strips, as asked */
         m->have_key = false;
+        m->direct = false;
         m->info.balanced = 0;
     }
+    if (direct) chunks = 1;                              /* nothing to overlap: one launch per strip */
     int rc = multi_reserve(m, W, H, chunks);
     if (rc) return rc;
     for (int g = 0; g < ngpu; ++g) { rc = rt_reset_timing(m->scenes[(size_t)g]); if (rc) return rc; }
     const double t0 = now_ms();
-    rc = multi_frame(m, cam, W, H, max_depth, chunks, true, true);
+    rc = multi_frame(m, cam, W, H, max_depth, chunks, true, true, direct);
     if (rc) return rc;
     m->info.frame_ms = now_ms() - t0;
+    m->info.transport = direct ? RT_MULTI_TRANSPORT_DIRECT : RT_MULTI_TRANSPORT_RCCL;
     m->info.chunks = chunks;
     const size_t image_bytes = (size_t)W * (size_t)H * 3 * sizeof(float);
-    HIP_OR_FAIL(hipSetDevice(0));
+    HIP_OR_FAIL(hipSetDevice(m->dev[0]));
     HIP_OR_FAIL(hipMemcpy(out_rgb, m->d_full, image_bytes, hipMemcpyDeviceToHost));
     /* per GPU: its kernels' time in this frame; and what the kernels may have had to tell the host (a HELP wait that timed
      * out: the image is exact, the caller is told) */
