@@ -321,6 +321,36 @@ def test_measured_partition_is_agreed_on_and_delivers_the_image(oracle):
     np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def _balance_direct_worker(rank, world, W, init_file, out_file):
+    sys.path.insert(0, ROOT)
+    import json
+    from tilecoderaytracer_amd.distributed import balance_direct
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    bounds, note = balance_direct(W, [1.0, 3.0, 2.0][rank], torch.device("cpu"))
+    json.dump({"bounds": bounds, "note": note}, open(f"{out_file}.{rank}.json", "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_transport_cuts_strips_of_equal_measured_kernel_time():
+    """bench.py's re-cut for the direct-store transport: no transfer to weigh, every rank ends up with the same share of the
+    measured kernel time, and every rank computes the same strips (tilecoderaytracer_amd.distributed.balance_direct)."""
+    import json
+    world, W = 3, 300
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out")
+        mp.spawn(_balance_direct_worker, args=(world, W, init_file, out_file), nprocs=world, join=True)
+        per_rank = [json.load(open(f"{out_file}.{r}.json")) for r in range(world)]
+    assert per_rank[0]["bounds"] == per_rank[1]["bounds"] == per_rank[2]["bounds"]
+    b = per_rank[0]["bounds"]
+    assert b[0][0] == 0 and b[-1][1] == W and all(b[r][1] == b[r + 1][0] for r in range(world - 1))
+    # columns 0-99 cost 0.01 each, 100-199 0.03, 200-299 0.02: 6 ms in all, 2 ms per rank
+    cost = np.concatenate([np.full(100, 0.01), np.full(100, 0.03), np.full(100, 0.02)])
+    shares = [cost[a:c].sum() for a, c in b]
+    assert max(shares) - min(shares) <= 0.031 and abs(sum(shares) - 6.0) < 1e-9
+    assert "kernel ms per rank [1.0, 3.0, 2.0]" in per_rank[0]["note"]
+
+
 def test_rt_render_multi_strip_arithmetic(oracle):
     """rt_render_multi (one process, N GPUs) on the CPU, with the oracle standing in for the
     kernel: every "GPU" renders the strip rt_strip_bounds gives it into its own strip-sized
