@@ -431,6 +431,29 @@ def test_render_multi_single_gpu(oracle):
     assert rc == capi.RT_ERR_INVALID
 
 
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_render_multi_random_scenes_and_shapes_on_one_device(oracle, monkeypatch, seed):
+    """rt_render_multi (create + measure + cut + render + destroy) with 2 ... 7 strips on the box's one device
+    (TCRT_MULTI_ONE_DEVICE=1), random scenes, image shapes down to fewer columns than GPUs: the strip arithmetic, the measured
+    cut and the direct stores on ragged sizes."""
+    import ctypes as C
+    from scene_gen import build_random, build_sphere_field
+    from tilecoderaytracer_amd import capi
+    monkeypatch.setenv("TCRT_MULTI_ONE_DEVICE", "1")
+    rng = np.random.RandomState(seed)
+    ngpu = int(rng.choice([2, 3, 4, 5, 7]))
+    W = int(rng.choice([1, 3, ngpu - 1, ngpu, 17, 64, 150]))
+    H, depth = int(rng.randint(1, 70)), int(rng.randint(0, 6))
+    if seed % 3 == 0:
+        mk = lambda s: build_sphere_field(s, seed, n_spheres=130, spread=60.0)
+    else:
+        mk = lambda s: build_random(s, seed, shadows=(seed % 2 == 0))
+    host, orc = mk(HostScene.empty()), mk(oracle.OracleScene())
+    out = np.full((W, H, 3), -3.0, np.float32)
+    capi.check(capi.load_library().rt_render_multi(host.desc, host.camera, W, H, depth, ngpu, out.ctypes.data))
+    assert_same(out, orc.render(W, H, depth), f"seed {seed}: {ngpu} strips of a {W} x {H} image, depth {depth}")
+
+
 def test_multi_handle_renders_frames_in_column_chunks(oracle):
     """rt_multi_create / rt_multi_render / rt_multi_destroy: scenes, streams, buffers (and, beyond one GPU, the
     communicator) persist across frames; every frame is rendered in `chunks` launches whose column chunks land in
