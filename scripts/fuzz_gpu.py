@@ -1,6 +1,7 @@
 """Randomised parity sweep, GPU kernel vs CPU oracle (development aid; the permanent cases live in tests/).
 
-usage: fuzz_gpu.py [first_seed=1000] [count=200] [only=0..3] [far=1] [bigfields=1] [option=value ...]
+usage: fuzz_gpu.py [first_seed=1000] [count=200] [only=0..3] [far=1] [bigfields=1] [multi=1] [option=value ...]
+multi=1: every scene through rt_render_multi with 2 ... 7 strips on this one device (TCRT_MULTI_ONE_DEVICE=1: measured cut, direct stores)
 far=1: every scene is a far-origin grazing scene (scene_gen.build_far_grazing) in a strip 8 columns wide and 4 096 ... 32 768 rows
 tall, whose rows around the middle hit the ground 1e4 ... 6e4 units away"""
 import os, sys, time
@@ -38,9 +39,24 @@ for seed in range(first, first + count):
     host = mk(HostScene.empty())
     rng.set_state(state)
     orc = mk(oracle_lib.OracleScene())
+    if kv.get("multi") == "1":
+        import ctypes as C
+        from tilecoderaytracer_amd import capi
+        os.environ["TCRT_MULTI_ONE_DEVICE"] = "1"
+        ngpu = int(rng.choice([2, 3, 4, 5, 7]))
+        got = np.full((W, H, 3), -3.0, np.float32)
+        capi.check(capi.load_library().rt_render_multi(host.desc, host.camera, W, H, depth, ngpu, got.ctypes.data))
+        want = orc.render(W, H, depth)
+        if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+            d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+            bad.append((seed, W, H, depth, len(d), d[0].tolist(), ngpu))
+            print("MISMATCH", bad[-1], flush=True)
+        if (seed - first) % 250 == 249:
+            print(f"... {seed - first + 1} scenes, {len(bad)} mismatching, {time.time() - t0:.0f} s", flush=True)
+        continue
     r = Renderer(host)
     for k, v in kv.items():                             # any other key=value: an rt_set_option for every scene (help=2 heavy=1 ...)
-        if k not in ("first_seed", "count", "only", "learn", "far", "bigfields"):
+        if k not in ("first_seed", "count", "only", "learn", "far", "bigfields", "multi"):
             r.set_option(k, int(v))
     if seed % 3 == 0:
         r.set_option("tile_z", int(2 ** rng.randint(0, 7)))
