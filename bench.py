@@ -523,12 +523,15 @@ def main(argv=None):
         direct = transport == "direct"
         shared = None
         if direct:                 # rank 0's image, mapped by every other rank (collective: raises on every rank or on none)
-            shared = SharedImage(W, H, dev)
-            shared_images.append(shared)
+            shared = [SharedImage(W, H, dev)]
+            shared_images.append(shared[0])
+            if overlap:            # a stream of frames alternates between two images
+                shared.append(SharedImage(W, H, dev))
+                shared_images.append(shared[1])
 
         def make_pipe(bounds=None, chunks=1):
             if direct:
-                return DirectStrips(shared, world, rank, dev, bounds=bounds,
+                return DirectStrips(shared, world, rank, dev, bounds=bounds, overlap=overlap,
                                     render_ptr=lambda address, a, b: renderer.render_device(W, H, depth, a, b, address, stream))
             pp = StripPipeline(W, H, world, rank, dev, render=None, overlap=overlap,
                                force_gather=args.force_dist, bounds=bounds, chunks=chunks, align=16)
@@ -688,11 +691,14 @@ def main(argv=None):
     # N > 1: the throughput of a STREAM of frames (gather of frame k under the render of frame k+1),
     # next to the single-frame headline; a different figure, labelled as such
     pipelined = None
-    if world > 1 and not args.no_pipelined and args.backend == "nccl":
-        pm = measure(args.workload, args.steps, max(args.warmup, 3), args.size, overlap=True)
+    if world > 1 and not args.no_pipelined:
+        pm = measure(args.workload, args.steps, max(args.warmup, 3), args.size, overlap=True, transport=m["transport"])
         pipelined = {
-            "what": "stream of independent frames: RCCL gather of frame k overlapped with the render of frame k+1 "
-                    "(two strip buffers); NOT the single-frame figure `value` reports",
+            "what": ("stream of independent frames: frame k+1 is rendered into a second shared image while the other ranks finish frame k "
+                     "(two images on rank 0, a frame's all-reduce waited for two frames later)" if m["transport"] == "direct" else
+                     "stream of independent frames: RCCL gather of frame k overlapped with the render of frame k+1 (two strip buffers)")
+                    + "; NOT the single-frame figure `value` reports",
+            "transport": m["transport"],
             "value": round(pm["W"] * pm["H"] * args.steps / pm["elapsed"] / 1e6, 3),
             "unit": "Mrays/s",
             "ms_per_step": round(pm["elapsed"] / args.steps * 1e3, 4),

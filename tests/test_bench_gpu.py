@@ -122,3 +122,4 @@ def test_bench_two_ranks_on_one_gpu_store_into_the_shared_image():
     assert "2 x-strips of" in c["partition"] and "straight into rank 0's image" in c["partition"]
     assert "kernel ms per rank" in c["partition_note"] and "rt_learn_tile_order" in c["partition_note"]
     assert "MB" in c["scaling_note"] and "cpu_baseline" not in j
+    assert j["pipelined"]["transport"] == "direct" and j["pipelined"]["value"] > 10.0 and "second shared image" in j["pipelined"]["what"]

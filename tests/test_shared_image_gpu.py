@@ -76,6 +76,52 @@ def test_ranks_render_into_one_shared_image(oracle, world, scene_name, W, H, dep
     np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def _stream_worker(rank, world, W, H, frames, init_file, out_file):
+    """A stream of frames through two shared images: frame k is rendered at depth k % 3 + 1 (a stale frame would show)."""
+    sys.path.insert(0, ROOT)
+    from tilecoderaytracer_amd import HostScene, Renderer
+    from tilecoderaytracer_amd.distributed import DirectStrips, SharedImage
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    renderer = Renderer(HostScene.named("builtin"), device=0)
+    images = [SharedImage(W, H, dev), SharedImage(W, H, dev)]
+    frame = {"k": 0}
+
+    def render_ptr(address, a, b):
+        renderer.render_device(W, H, frame["k"] % 3 + 1, a, b, address, stream)
+        frame["k"] += 1
+
+    pipe = DirectStrips(images, world, rank, dev, render_ptr, bounds=[(0, 50), (50, W)], overlap=True)
+    for _ in range(frames):
+        pipe.step()
+    img = pipe.image(W)                                  # drains: the last frame's all-reduce has completed
+    if rank == 0:
+        np.save(out_file, img.cpu().numpy())
+    dist.barrier()
+    if rank != 0:
+        for image in images:
+            image.close()
+    dist.barrier()
+    if rank == 0:
+        for image in images:
+            image.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames", [4, 5])
+def test_a_stream_of_frames_alternates_between_two_shared_images(oracle, frames):
+    W, H = 120, 64
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.npy")
+        mp.spawn(_stream_worker, args=(2, W, H, frames, init_file, out_file), nprocs=2, join=True)
+        got = np.load(out_file)
+    want = oracle.OracleScene.named("builtin").render(W, H, (frames - 1) % 3 + 1)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_shared_image_handle_and_errors():
     """create / destroy in one process; NULL arguments and an empty image are refused."""

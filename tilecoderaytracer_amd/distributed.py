@@ -393,33 +393,55 @@ class DirectStrips:
     current stream), then a one-word all-reduce in stream order behind it -- when a rank's all-reduce has completed, every
     rank's kernel of that frame has, so the frame is whole in the owner's HBM, and the next frame's kernel starts behind it:
     one frame at a time, with no host synchronisation per frame (RCCL; gloo's collectives run on the host, so there the
-    stream is drained first)."""
+    stream is drained first).
 
-    def __init__(self, shared, world, rank, device, render_ptr, bounds=None):
-        self.shared, self.world, self.rank, self.device, self.render_ptr = shared, world, rank, device, render_ptr
-        self.bounds = [tuple(b) for b in (bounds if bounds is not None else equal_bounds(shared.W, world))]
-        assert len(self.bounds) == world and self.bounds[0][0] == 0 and self.bounds[-1][1] == shared.W
+    overlap=True with TWO shared images: a stream of independent frames.  Frame k goes to image k % 2 and its all-reduce is
+    only waited for before frame k + 2 is rendered into the same image, so a rank's next kernel starts as soon as its own
+    last one is done, whatever the other ranks are doing (StripPipeline's pipelined mode without the transfers)."""
+
+    def __init__(self, shared, world, rank, device, render_ptr, bounds=None, overlap=False):
+        self.shareds = list(shared) if isinstance(shared, (list, tuple)) else [shared]
+        self.shared = self.shareds[0]
+        self.world, self.rank, self.device, self.render_ptr = world, rank, device, render_ptr
+        self.overlap = bool(overlap) and len(self.shareds) > 1
+        W = self.shared.W
+        self.bounds = [tuple(b) for b in (bounds if bounds is not None else equal_bounds(W, world))]
+        assert len(self.bounds) == world and self.bounds[0][0] == 0 and self.bounds[-1][1] == W
         assert all(self.bounds[r][1] == self.bounds[r + 1][0] for r in range(world - 1))
         self.x0, self.x1 = self.bounds[rank]
         self.strip = max(self.x1 - self.x0, 1)
         self._host_collectives = dist.get_backend() != "nccl"
-        self._flag = torch.zeros(1, dtype=torch.int32, device=_collective_device(device))
+        self._flags = [torch.zeros(1, dtype=torch.int32, device=_collective_device(device)) for _ in self.shareds]
+        self.pending = [None] * len(self.shareds)
         self.k = 0
 
+    def _wait(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+
     def step(self):
+        b = self.k % len(self.shareds) if self.overlap else 0
         self.k += 1
+        self._wait(b)
         if self.x1 > self.x0:
-            self.render_ptr(self.shared.column_ptr(self.x0), self.x0, self.x1)
+            self.render_ptr(self.shareds[b].column_ptr(self.x0), self.x0, self.x1)
         if self._host_collectives:
             torch.cuda.synchronize(self.device)
-        dist.all_reduce(self._flag)
+        if self.overlap:
+            self.pending[b] = dist.all_reduce(self._flags[b], async_op=True)
+        else:
+            dist.all_reduce(self._flags[b])
 
     def drain(self):
-        pass
+        for b in range(len(self.pending)):
+            self._wait(b)
 
     def image(self, W=None):
-        """Rank 0 (the owner): the whole frame, as StripPipeline.image() gives it; None elsewhere."""
-        return self.shared.tensor() if self.rank == self.shared.owner else None
+        """Rank 0 (the owner): the last frame, as StripPipeline.image() gives it; None elsewhere."""
+        self.drain()
+        last = (self.k - 1) % len(self.shareds) if (self.overlap and self.k > 0) else 0
+        return self.shareds[last].tensor() if self.rank == self.shared.owner else None
 
     def describe(self):
         eq = list(self.bounds) == equal_bounds(self.shared.W, self.world)
