@@ -33,6 +33,16 @@ warm-up steps are untimed; the K timed steps all run the final partition.  The t
 under the render of frame k+1) is measured afterwards and reported beside the
 headline as `pipelined`, labelled as a different figure.
 
+TRANSPORTS (--transport, N > 1).  The strips can reach rank 0 in two ways, and which is faster is a property of the
+machine: "rccl" = strip buffers sent with RCCL as described above; "direct" = rank 0's image is shared with the other
+ranks over HIP IPC (rt_shared_image_*, include/rt_capi.h) and every rank's kernel stores its strip straight into it --
+the reference's ranks writing into the one `pixels` array (src/RayTracer.cpp:904-923, 1188-1196) -- with a one-word
+all-reduce in stream order behind the kernel as the frame's fence; strips of equal measured kernel time.  The default,
+"auto", times K steps of EACH (own warm-up, own partition), reports the faster as the headline (`config.transport`) and
+the other beside it (`config.other_transport`), and compares both images, bit for bit, with the frame rank 0's GPU
+renders alone.  --backend gloo with TCRT_BENCH_ONE_DEVICE=1 is a rehearsal aid: several ranks on ONE GPU (RCCL refuses
+that), direct transport only -- the whole N > 1 sequence on a one-GPU box (tests/test_bench_gpu.py).
+
 Timed region: barrier + synchronize, K steps (kernel + gather), barrier +
 synchronize; MAX over ranks.  The framebuffer stays in HBM (inputs -- the
 scene tables -- are resident before the region starts); no device-to-host copy
