@@ -481,6 +481,9 @@ def main(argv=None):
             sys.exit(self_launch(args, argv))          # one process per GPU: started from here
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
+    # (this pool's driver shares device memory between processes -- RCCL's buffers, rt_shared_image_* -- through dmabuf only;
+    # the variable is read when the HIP runtime starts, i.e. below)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from tilecoderaytracer_amd import HostScene, Renderer
