@@ -703,9 +703,16 @@ def main(argv=None):
             grid["other_transport"] = other_transport(g_other, g_steps)
     # N > 1: the throughput of a STREAM of frames (gather of frame k under the render of frame k+1),
     # next to the single-frame headline; a different figure, labelled as such
-    pipelined = None
+    pipelined, pm = None, None
     if world > 1 and not args.no_pipelined:
-        pm = measure(args.workload, args.steps, max(args.warmup, 3), args.size, overlap=True, transport=m["transport"])
+        try:
+            pm = measure(args.workload, args.steps, max(args.warmup, 3), args.size, overlap=True, transport=m["transport"])
+        except RuntimeError as e:
+            if "cannot be shared" not in str(e):             # (SharedImage: raised on every rank or on none)
+                raise
+            pm = None
+            pipelined = {"error": f"second shared image unavailable: {e}"}
+    if pm is not None:
         pipelined = {
             "what": ("stream of independent frames: frame k+1 is rendered into a second shared image while the other ranks finish frame k "
                      "(two images on rank 0, a frame's all-reduce waited for two frames later)" if m["transport"] == "direct" else
