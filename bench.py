@@ -698,6 +698,11 @@ def main(argv=None):
             "mode": ("single frame: the kernels store into rank 0's image" if g["transport"] == "direct" else "single frame: render, then gather")
                     if world > 1 else "one launch per frame",
         }
+        # the north star's own wording: the sphere-grid figure "as absolute numbers and as fraction of the HBM-write roofline"
+        # (12 B per pixel over the whole job's step time, against the N GPUs' aggregate HBM peak)
+        grid_gbs = BYTES_PER_PIXEL * g["W"] * g["H"] * g_steps / g["elapsed"] / 1e9
+        grid["hbm_write_roofline"] = {"achieved": round(grid_gbs, 3), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                      "frac": round(grid_gbs / (HBM_PEAK_GBS * world), 6)}
         if use_dist:
             grid["transport"] = g["transport"]
             grid["other_transport"] = other_transport(g_other, g_steps)
@@ -864,6 +869,16 @@ def main(argv=None):
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = repr(e)
+            if grid is not None:
+                # "... next to the reference CPU path timed on the node's own host cores (core count stated) in the same run":
+                # the oracle on the sphere-grid frame too, a bounded sample (one run of ~1 s on all cores), every sampled
+                # column compared with the GPU's frame
+                try:
+                    grid_image = g["renderer"].render(g["W"], g["H"], g["depth"])
+                    grid["cpu_baseline"] = cpu_baseline(g["scene_name"], g["W"], g["H"], g["depth"], 64, grid_image, repeats=1)
+                    del grid_image
+                except Exception as e:
+                    grid["cpu_baseline_error"] = repr(e)
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

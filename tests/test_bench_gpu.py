@@ -36,6 +36,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert c["parity"]["pixels_compared"] > 0 and c["parity"]["max_abs_delta"] == 0.0 and c["parity"]["pixels_over_1e-6"] == 0
     assert j["config"]["max_delta_vs_cpu_ref"] == 0.0
     assert j["sphere_grid"]["value"] > 100.0
+    g = j["sphere_grid"]
+    assert abs(g["hbm_write_roofline"]["frac"] - g["hbm_write_roofline"]["achieved"] / 8000.0) < 1e-5 and g["hbm_write_roofline"]["peak"] == 8000.0
+    assert g["cpu_baseline"]["value"] > 0 and g["cpu_baseline"]["cores"] >= 1 and g["cpu_baseline"]["parity"]["max_abs_delta"] == 0.0
+    assert g["cpu_baseline"]["parity"]["pixels_compared"] > 0
     sec = j["secondary"]
     assert sec["rays_per_pixel"] > 1.0 and sec["total_rays_per_s"] > j["value"] * 1e6
     assert 0.0 < sec["test_flop_frac_of_valu_peak"] < 1.0
