@@ -405,6 +405,15 @@ def test_4096_grid16_depth8_every_pixel(oracle):
     _assert_every_pixel(oracle, img, lambda: oracle.OracleScene.grid(16, True), 8, "grid-16 depth 8")
 
 
+def test_4096_two_mirrors_depth4_every_pixel(oracle):
+    """The reference's SCENE 2 (3 920 objects; `bench.py --workload twomirrors`, the global-memory tables' kernel) at 4096^2, depth 4:
+    all 16.7 M pixels against the oracle (about a minute of the box's 16 cores)."""
+    r = Renderer(HostScene.named("twomirrors"))
+    img = r.render(4096, 4096, 4)
+    assert r.launch_info().kernel == b"rt_render_kernel_large"
+    _assert_every_pixel(oracle, img, lambda: oracle.OracleScene.named("twomirrors"), 4, "two mirrors depth 4")
+
+
 def test_render_device_into_torch_memory(oracle):
     """The device-pointer entry point used by bench.py and the multi-GPU path."""
     import torch
