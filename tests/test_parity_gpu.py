@@ -377,15 +377,15 @@ def test_4096_grid16_depth8_columns(oracle):
         assert_same(img[x0:x0 + 1], want, f"column {x0}")
 
 
-def _assert_every_pixel(oracle, img, make_oracle_scene, depth, what):
-    """All 4096 x 4096 pixels of `img` against the oracle, 64 column blocks dealt to the host's cores
+def _assert_every_pixel(oracle, img, make_oracle_scene, depth, what, size=4096):
+    """All size x size pixels of `img` against the oracle, 64-column blocks dealt to the host's cores
     (the C oracle releases the GIL; one scene per worker call)."""
     from concurrent.futures import ThreadPoolExecutor
     workers = max(1, min(16, len(os.sched_getaffinity(0))))
-    bounds = [(k * 64, (k + 1) * 64) for k in range(64)]
+    bounds = [(k * 64, (k + 1) * 64) for k in range(size // 64)]
 
     def work(b):
-        return make_oracle_scene().render(4096, 4096, depth, b[0], b[1])
+        return make_oracle_scene().render(size, size, depth, b[0], b[1])
 
     with ThreadPoolExecutor(max_workers=workers) as pool:
         for (x0, x1), want in zip(bounds, pool.map(work, bounds)):
@@ -944,6 +944,10 @@ def test_8192_builtin_as_eight_strips(oracle):
     cols = [1, 513, 1023, 1025, 2047, 2049, 3071, 3073, 4095, 4097, 5119, 5121, 6143, 6145, 7167, 7169, 8191]
     for x0, got in _oracle_columns(oracle, lambda: oracle.OracleScene.builtin(), W, H, depth, cols).items():
         assert_same(full[x0:x0 + 1].cpu().numpy(), got, f"column {x0}")
+    # and every one of the 67 108 864 pixels against the oracle (five seconds of the box's 16 cores)
+    host_image = full.cpu().numpy()
+    del full, strip
+    _assert_every_pixel(oracle, host_image, lambda: oracle.OracleScene.builtin(), depth, "8192^2 built-in", size=8192)
 
 
 def test_8192_grid32_as_eight_strips(oracle):
