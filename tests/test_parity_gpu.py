@@ -463,6 +463,18 @@ def test_render_multi_random_scenes_and_shapes_on_one_device(oracle, monkeypatch
     assert_same(out, orc.render(W, H, depth), f"seed {seed}: {ngpu} strips of a {W} x {H} image, depth {depth}")
 
 
+def test_render_multi_the_references_simulator_configuration(oracle, monkeypatch):
+    """IS_FOR_SIMULATION (src/rt_project_parameters.h:45-52, src/RayTracer.h:64-66): 2 cores, 5 x 5 pixels -- the reference's own
+    way of running its parallel path without the hardware; here two strips on the one device, the shipped depth 50."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    monkeypatch.setenv("TCRT_MULTI_ONE_DEVICE", "1")
+    host = HostScene.builtin()
+    out = np.zeros((5, 5, 3), np.float32)
+    capi.check(capi.load_library().rt_render_multi(host.desc, host.camera, 5, 5, 50, 2, out.ctypes.data))
+    assert_same(out, oracle.OracleScene.builtin().render(5, 5, 50), "2 cores, 5 x 5 pixels")
+
+
 def test_multi_handle_renders_frames_in_column_chunks(oracle):
     """rt_multi_create / rt_multi_render / rt_multi_destroy: scenes, streams, buffers (and, beyond one GPU, the
     communicator) persist across frames; every frame is rendered in `chunks` launches whose column chunks land in

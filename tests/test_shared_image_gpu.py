@@ -61,6 +61,7 @@ def _direct_worker(rank, world, scene_name, W, H, depth, bounds, frames, init_fi
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,scene_name,W,H,depth,bounds", [
+    (2, "builtin", 5, 5, 50, None),                                       # the reference's own rehearsal shape: IS_FOR_SIMULATION, 2 cores, 5 x 5 pixels (src/rt_project_parameters.h:45-52)
     (2, "builtin", 128, 96, 4, None),                                     # equal strips
     (2, "builtin", 150, 70, 4, [(0, 37), (37, 150)]),                     # uneven, not on tile boundaries
     (3, "grid16", 96, 64, 8, [(0, 40), (40, 40), (40, 96)]),              # an empty strip in the middle; the clustered-scene kernel
