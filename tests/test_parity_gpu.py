@@ -463,6 +463,58 @@ def test_render_multi_random_scenes_and_shapes_on_one_device(oracle, monkeypatch
     assert_same(out, orc.render(W, H, depth), f"seed {seed}: {ngpu} strips of a {W} x {H} image, depth {depth}")
 
 
+@pytest.mark.parametrize("ngpu", [2, 3, 5])
+def test_multi_handle_strip_buffer_transport_and_the_trial_on_one_device(oracle, monkeypatch, ngpu):
+    """The strip-buffer transport of the one-process path with SEVERAL strips -- per-GPU strip buffers, column chunks, a kernel-done
+    event per chunk, the transfer on the GPU's communication stream while the next chunk renders, the measured cut with its send
+    term -- and the automatic choice between it and the direct stores (two frames of each on its own cut), all on the box's one
+    device: TCRT_MULTI_ONE_DEVICE=2 stands local device-to-device copies in for ncclSend / ncclRecv (csrc/rt_multi.hip, LOOPBACK).
+    RCCL itself needs two GPUs."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    lib = capi.load_library()
+    monkeypatch.setenv("TCRT_MULTI_ONE_DEVICE", "2")
+    host, orc = HostScene.named("grid16"), oracle.OracleScene.named("grid16")
+    W, H, depth = 333, 80, 5
+    want = orc.render(W, H, depth)
+    m = C.c_void_p()
+    capi.check(lib.rt_multi_create(host.desc, ngpu, C.byref(m)))
+    try:
+        info = capi.RtMultiInfo()
+        out = np.zeros((W, H, 3), dtype=np.float32)
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))            # automatic: both measured, the trial
+        assert_same(out, want, "automatic transport")
+        capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+        assert info.transport in (1, 2) and info.balanced == 1 and info.trial_frame_ms[0] > 0.0 and info.trial_frame_ms[1] > 0.0
+        assert (info.transport == 2) == (info.trial_frame_ms[1] < info.trial_frame_ms[0])
+        assert info.bounds[0] == 0 and info.bounds[ngpu] == W
+        for transport in (1, 2, 1):
+            capi.check(lib.rt_multi_set_option(m, b"transport", transport))
+            out[:] = 0
+            capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))        # re-measured for that transport
+            assert_same(out, want, f"transport {transport}, measured cut")
+            capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+            assert info.transport == transport and info.balanced == 1 and 1 <= info.chunks <= 8
+            if transport == 1:
+                assert info.measured_gather_ms > 0.0
+        # strip buffers with an explicit chunk count on equal strips, then the caller's own cut (an empty strip in it) in 7 chunks
+        for chunks in (1, 5, 64):
+            out[:] = 0
+            capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, chunks, out.ctypes.data))
+            assert_same(out, want, f"equal strips, {chunks} chunks")
+            capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+            assert info.transport == 1 and info.chunks == chunks and info.balanced == 0
+        cut = [0] + [41] * (ngpu - 1) + [W]
+        capi.check(lib.rt_multi_set_bounds(m, W, (C.c_int * (ngpu + 1))(*cut), 7))
+        out[:] = 0
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+        assert_same(out, want, "caller's strips in 7 chunks")
+        capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+        assert [info.bounds[g] for g in range(ngpu + 1)] == cut and info.chunks == 7 and info.transport == 1
+    finally:
+        capi.check(lib.rt_multi_destroy(m))
+
+
 def test_render_multi_the_references_simulator_configuration(oracle, monkeypatch):
     """IS_FOR_SIMULATION (src/rt_project_parameters.h:45-52, src/RayTracer.h:64-66): 2 cores, 5 x 5 pixels -- the reference's own
     way of running its parallel path without the hardware; here two strips on the one device, the shipped depth 50."""
