@@ -39,10 +39,10 @@ for seed in range(first, first + count):
     host = mk(HostScene.empty())
     rng.set_state(state)
     orc = mk(oracle_lib.OracleScene())
-    if kv.get("multi") == "1":
+    if kv.get("multi") in ("1", "2"):           # 2: LOOPBACK -- the strip-buffer transport and the trial too
         import ctypes as C
         from tilecoderaytracer_amd import capi
-        os.environ["TCRT_MULTI_ONE_DEVICE"] = "1"
+        os.environ["TCRT_MULTI_ONE_DEVICE"] = kv["multi"]
         ngpu = int(rng.choice([2, 3, 4, 5, 7]))
         got = np.full((W, H, 3), -3.0, np.float32)
         capi.check(capi.load_library().rt_render_multi(host.desc, host.camera, W, H, depth, ngpu, got.ctypes.data))
