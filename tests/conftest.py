@@ -9,6 +9,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# device memory shared between processes (rt_shared_image_*, RCCL) goes through dmabuf on this pool's driver; the variable is
+# read when a HIP runtime starts -- here, before torch brings one in, and inherited by every process the tests start
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 # torch first: it carries its own copy of the HIP runtime, and a process that has already
 # initialised the system one through libtcrt.so (DT_NEEDED /opt/rocm/lib/libamdhip64.so) finds
 # "No HIP GPUs" when torch initialises afterwards; the other order works (seen on the GPU box
