@@ -61,6 +61,22 @@ def test_library_exports_every_declared_symbol():
         assert int(re.search(r"#define %s (\d+)" % macro, text).group(1)) == fn()
 
 
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers compile as C99 with warnings as errors (a maintainer of the reference, or any FFI
+    generator, includes them from C)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "rt_capi.h"\n#include "rt_capi_tuning.h"\n'
+                   "int main(void) { unsigned char h[RT_SHARED_HANDLE_BYTES]; rt_multi_info i; (void)h; (void)i;\n"
+                   "  return (RT_MULTI_TRANSPORT_DIRECT == 2 && RT_CAPI_VERSION == 4) ? 0 : 1; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_struct_sizes_match_the_header():
     # field-for-field mirrors; sizes as laid out by the C compiler
     assert C.sizeof(capi.RtObjectDesc) == 4 * (4 + 3 + 3 + 3 + 2 + 3 + 12 + 2 + 1)
