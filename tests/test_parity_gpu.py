@@ -515,6 +515,40 @@ def test_multi_handle_strip_buffer_transport_and_the_trial_on_one_device(oracle,
         capi.check(lib.rt_multi_destroy(m))
 
 
+def test_threads_share_a_handle_and_use_their_own(oracle):
+    """calls on ONE handle from several threads serialise on its mutex (every thread gets its own
+    strip, whole and exact); handles of different threads are independent (ctypes releases the GIL: the calls really overlap)."""
+    from concurrent.futures import ThreadPoolExecutor
+    W, H, depth = 160, 120, 5
+    shared = Renderer(HostScene.builtin())
+    want_builtin = oracle.OracleScene.builtin().render(W, H, depth)
+
+    def strip_on_the_shared_handle(k):
+        x0, x1 = k * 20, (k + 1) * 20
+        for _ in range(6):
+            got = shared.render(W, H, depth, x0, x1)
+            if not np.array_equal(got.view(np.uint32), want_builtin[x0:x1].view(np.uint32)):
+                return f"strip {k} of the shared handle"
+        return None
+
+    names = ["builtin", "grid9", "grid16", "twomirrors"]
+    wants = {n: oracle.OracleScene.named(n).render(96, 64, 4) for n in names}
+
+    def own_handle(k):
+        name = names[k % len(names)]
+        r = Renderer(HostScene.named(name))
+        for _ in range(4):
+            got = r.render(96, 64, 4)
+            if not np.array_equal(got.view(np.uint32), wants[name].view(np.uint32)):
+                return f"{name} on thread {k}'s own handle"
+        return None
+
+    with ThreadPoolExecutor(max_workers=16) as pool:
+        jobs = [pool.submit(strip_on_the_shared_handle, k) for k in range(8)] + [pool.submit(own_handle, k) for k in range(8)]
+        wrong = [j.result() for j in jobs if j.result()]
+    assert not wrong, wrong
+
+
 def test_render_multi_the_references_simulator_configuration(oracle, monkeypatch):
     """IS_FOR_SIMULATION (src/rt_project_parameters.h:45-52, src/RayTracer.h:64-66): 2 cores, 5 x 5 pixels -- the reference's own
     way of running its parallel path without the hardware; here two strips on the one device, the shipped depth 50."""
