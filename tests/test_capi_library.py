@@ -153,6 +153,21 @@ def test_no_gpu_means_no_render(have_gpu):
     assert rc == capi.RT_ERR_NO_DEVICE and not out.any()
 
 
+def test_no_gpu_means_no_shared_image(have_gpu):
+    """rt_shared_image_* without a device: an error code and a message, no image and no crash; NULL arguments are refused first."""
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    lib = capi.load_library()
+    handle = C.create_string_buffer(64)
+    p = C.c_void_p(1234)
+    assert lib.rt_shared_image_create(0, 1 << 20, None, handle) == capi.RT_ERR_INVALID
+    rc = lib.rt_shared_image_create(0, 1 << 20, C.byref(p), handle)
+    assert rc != capi.RT_OK and p.value is None and lib.rt_last_error()
+    rc = lib.rt_shared_image_open(0, handle.raw, C.byref(p))
+    assert rc != capi.RT_OK and p.value is None
+    assert lib.rt_shared_image_close(0, None) == capi.RT_OK and lib.rt_shared_image_destroy(0, None) == capi.RT_OK
+
+
 @pytest.mark.parametrize("name", ["grid32", "grid16", "grid9", "twomirrors"])
 def test_packing_a_clustered_scene_needs_no_gpu_and_then_says_so(have_gpu, name):
     """rt_scene_create packs the tables -- sphere clusters, item tables, and for the 1 024-sphere grid the SHADOW VOXELS
