@@ -351,6 +351,77 @@ def test_direct_transport_cuts_strips_of_equal_measured_kernel_time():
     assert "kernel ms per rank [1.0, 3.0, 2.0]" in per_rank[0]["note"]
 
 
+class _FileSharedImage:
+    """Stands in for SharedImage on a machine without a GPU: the image is a file both rank processes map (shared memory between
+    processes, as HIP IPC gives the GPUs); same attributes and methods as tilecoderaytracer_amd.distributed.SharedImage."""
+
+    def __init__(self, path, W, H, owner=0):
+        self.W, self.H, self.owner = W, H, owner
+        self.map = np.memmap(path, dtype=np.float32, mode="r+", shape=(W, H, 3))
+        self.ptr = self.map.ctypes.data
+
+    def column_ptr(self, x):
+        return self.ptr + int(x) * self.H * 12
+
+    def tensor(self):
+        return torch.from_numpy(np.asarray(self.map))
+
+
+def _direct_cpu_worker(rank, world, W, H, bounds, overlap, frames, paths, init_file, out_file):
+    """DirectStrips as bench.py drives it, the oracle standing in for the kernel: it `renders` its strip and the bytes go where
+    the kernel would store them -- through the address DirectStrips hands to render_ptr."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle_lib
+    from tilecoderaytracer_amd.distributed import DirectStrips
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    scene = oracle_lib.OracleScene.builtin()
+    images = [_FileSharedImage(p, W, H) for p in paths]
+    frame = {"k": 0}
+
+    def render_ptr(address, a, b):
+        strip = np.ascontiguousarray(scene.render(W, H, frame["k"] % 3, a, b))      # frame k at depth k % 3: a stale frame would show
+        C.memmove(address, strip.ctypes.data, strip.nbytes)
+        frame["k"] += 1
+
+    pipe = DirectStrips(images if overlap else images[0], world, rank, torch.device("cpu"), render_ptr, bounds=bounds, overlap=overlap)
+    assert (pipe.x0, pipe.x1) == tuple((bounds or [(r * -(-W // world), min((r + 1) * -(-W // world), W)) for r in range(world)])[rank])
+    for _ in range(frames):
+        pipe.step()
+        if pipe.x1 == pipe.x0:
+            frame["k"] += 1                                  # (a rank with an empty strip renders nothing but counts the frame)
+    img = pipe.image(W)
+    assert (img is None) == (rank != 0)
+    if rank == 0:
+        np.save(out_file, img.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,bounds,overlap,frames", [
+    (2, 40, None, False, 3),
+    (2, 37, [(0, 9), (9, 37)], False, 4),
+    (3, 30, [(0, 12), (12, 12), (12, 30)], False, 2),          # an empty strip
+    (2, 40, None, True, 4),                                    # a stream of frames through two images: the last one is in image 1
+    (3, 33, [(0, 5), (5, 20), (20, 33)], True, 5),             # ... in image 0
+])
+def test_direct_strips_deliver_the_frame_without_a_gather(oracle, world, W, bounds, overlap, frames):
+    """The direct transport's host logic over gloo, world size 2 and 3 (tilecoderaytracer_amd.distributed.DirectStrips): every rank
+    stores its strip into the one shared image, a one-word all-reduce per frame is the fence, a stream of frames alternates
+    between two images -- rank 0 ends up holding exactly the last frame."""
+    H = 12
+    with tempfile.TemporaryDirectory() as d:
+        paths = [os.path.join(d, f"image{i}.f32") for i in range(2 if overlap else 1)]
+        for p in paths:
+            np.full((W, H, 3), -7.0, np.float32).tofile(p)
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.npy")
+        mp.spawn(_direct_cpu_worker, args=(world, W, H, bounds, overlap, frames, paths, init_file, out_file), nprocs=world, join=True)
+        got = np.load(out_file)
+    want = oracle.OracleScene.builtin().render(W, H, (frames - 1) % 3)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_rt_render_multi_strip_arithmetic(oracle):
     """rt_render_multi (one process, N GPUs) on the CPU, with the oracle standing in for the
     kernel: every "GPU" renders the strip rt_strip_bounds gives it into its own strip-sized

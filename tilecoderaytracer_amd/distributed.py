@@ -426,8 +426,8 @@ class DirectStrips:
         self._wait(b)
         if self.x1 > self.x0:
             self.render_ptr(self.shareds[b].column_ptr(self.x0), self.x0, self.x1)
-        if self._host_collectives:
-            torch.cuda.synchronize(self.device)
+        if self._host_collectives and torch.device(self.device).type == "cuda":
+            torch.cuda.synchronize(self.device)               # (the kernel must be done before a host-side collective says so)
         if self.overlap:
             self.pending[b] = dist.all_reduce(self._flags[b], async_op=True)
         else:
