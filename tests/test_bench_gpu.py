@@ -127,3 +127,20 @@ def test_bench_two_ranks_on_one_gpu_store_into_the_shared_image():
     assert "kernel ms per rank" in c["partition_note"] and "rt_learn_tile_order" in c["partition_note"]
     assert "MB" in c["scaling_note"] and "cpu_baseline" not in j
     assert j["pipelined"]["transport"] == "direct" and j["pipelined"]["value"] > 10.0 and "second shared image" in j["pipelined"]["what"]
+
+
+@pytest.mark.gpu
+def test_bench_prefers_the_transport_whose_image_is_right():
+    """Correctness before speed: with one pixel of the direct transport's image spoiled (TCRT_BENCH_CORRUPT, a testing aid) the
+    headline is the strip-buffer transport whatever the times were, and the line says why."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--force-dist",
+                          "--no-cpu-baseline", "--no-extra", "--workload", "grid16d8", "--size", "512"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, TCRT_BENCH_CORRUPT="direct"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    c = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])["config"]
+    assert c["transport"] == "rccl" and c["gathered_image_vs_one_gpu_frame"] == SAME
+    other = c["other_transport"]
+    assert other["transport"] == "direct" and other["gathered_image_vs_one_gpu_frame"]["pixels_differing"] == 1
+    # (on one GPU the direct transport is the faster one -- no gather-to-self -- so the note must be there)
+    if other["ms_per_step"] < json.loads([l for l in out.stdout.splitlines() if l.strip()][0])["ms_per_step"]:
+        assert "differs from one GPU's frame" in c["transport_note"]
