@@ -660,7 +660,38 @@ def main(argv=None):
                     continue
                 raise
         done.sort(key=lambda r: r["elapsed"])
-        return done[0], (done[1] if len(done) > 1 else None), note
+        first, other = done[0], (done[1] if len(done) > 1 else None)
+        # The multi-GPU path's own parity property, measured in this run and outside the timed regions: the image the strips ended
+        # up in on rank 0 is, bit for bit, what ONE GPU renders as one frame (dx = x / W uses the global x; the one-GPU
+        # frame is what tests/test_parity_gpu.py compares with the oracle).  Correctness before speed: a faster transport whose
+        # image differs does not become the headline while the other one's is right (rank 0 checks, every rank learns the decision).
+        swap = 0
+        if rank == 0:
+            try:
+                whole = torch.empty((first["W"], first["H"], 3), dtype=torch.float32, device=dev)
+                first["renderer"].render_device(first["W"], first["H"], first["depth"], 0, first["W"], whole.data_ptr(), stream)
+                torch.cuda.synchronize(dev)
+                for r in (first, other):
+                    if r is None:
+                        continue
+                    gathered = r["pipe"].image(r["W"])
+                    if os.environ.get("TCRT_BENCH_CORRUPT") == r["transport"]:       # testing aid: spoil one pixel of that transport's image
+                        gathered[0, 0, 0] += 1.0
+                    differ = int((gathered[:r["W"]].view(torch.int32) != whole.view(torch.int32)).any(dim=2).sum())      # bit patterns
+                    r["image_check"] = {"pixels_compared": r["W"] * r["H"], "pixels_differing": differ, "identical": differ == 0}
+                del whole
+            except Exception as e:
+                first["image_check"] = {"error": repr(e)}
+            ok_first = first.get("image_check", {}).get("identical", True)
+            ok_other = other is not None and other.get("image_check", {}).get("identical", False)
+            swap = 1 if (not ok_first and ok_other) else 0
+        decision = torch.tensor([swap], dtype=torch.int32, device=cdev)
+        dist.broadcast(decision, src=0)
+        if int(decision[0]) == 1:
+            first, other = other, first
+            note = ((note + "; ") if note else "") + (
+                f"the {other['transport']} transport was faster but its image differs from one GPU's frame: {first['transport']} is the headline")
+        return first, other, note
 
     def transport_words(r):
         if r["transport"] == "direct":
@@ -677,38 +708,6 @@ def main(argv=None):
 
     m, m_other, transport_note = measure_transports(args.workload, args.steps, args.warmup, args.size)
 
-    # The multi-GPU path's own parity property, measured in this run and outside the timed regions: the image the strips ended up
-    # in on rank 0 is, bit for bit, what ONE GPU renders as one frame (dx = x / W uses the global x; the one-GPU
-    # frame is what tests/test_parity_gpu.py compares with the oracle).  Correctness before speed: a faster transport whose image
-    # differs does not become the headline while the other one's is right (rank 0 checks, every rank learns the decision).
-    image_checks = {}
-    if use_dist:
-        swap = 0
-        if rank == 0:
-            try:
-                whole = torch.empty((m["W"], m["H"], 3), dtype=torch.float32, device=dev)
-                m["renderer"].render_device(m["W"], m["H"], m["depth"], 0, m["W"], whole.data_ptr(), stream)
-                torch.cuda.synchronize(dev)
-                for r in (m, m_other):
-                    if r is None:
-                        continue
-                    gathered = r["pipe"].image(r["W"])
-                    if os.environ.get("TCRT_BENCH_CORRUPT") == r["transport"]:       # testing aid: spoil one pixel of that transport's image
-                        gathered[0, 0, 0] += 1.0
-                    differ = int((gathered[:r["W"]].view(torch.int32) != whole.view(torch.int32)).any(dim=2).sum())      # bit patterns
-                    image_checks[r["transport"]] = {"pixels_compared": r["W"] * r["H"], "pixels_differing": differ, "identical": differ == 0}
-                del whole
-            except Exception as e:
-                image_checks[m["transport"]] = {"error": repr(e)}
-            ok_first = image_checks.get(m["transport"], {}).get("identical", True)
-            ok_other = m_other is not None and image_checks.get(m_other["transport"], {}).get("identical", False)
-            swap = 1 if (not ok_first and ok_other) else 0
-        decision = torch.tensor([swap], dtype=torch.int32, device=cdev)
-        dist.broadcast(decision, src=0)
-        if int(decision[0]) == 1:
-            m, m_other = m_other, m
-            transport_note = ((transport_note + "; ") if transport_note else "") + (
-                f"the {m_other['transport']} transport was faster but its image differs from one GPU's frame: {m['transport']} is the headline")
     scene_name, W, H, depth, cfg_note = m["scene_name"], m["W"], m["H"], m["depth"], m["cfg_note"]
     host, renderer, x0, x1, strip = m["host"], m["renderer"], m["x0"], m["x1"], m["strip"]
     elapsed, kernel_ms = m["elapsed"], m["kernel_ms"]
@@ -738,7 +737,10 @@ def main(argv=None):
                                       "frac": round(grid_gbs / (HBM_PEAK_GBS * world), 6)}
         if use_dist:
             grid["transport"] = g["transport"]
+            grid["gathered_image_vs_one_gpu_frame"] = g.get("image_check")
             grid["other_transport"] = other_transport(g_other, g_steps)
+            if g_other is not None:
+                grid["other_transport"]["gathered_image_vs_one_gpu_frame"] = g_other.get("image_check")
     # N > 1: the throughput of a STREAM of frames (gather of frame k under the render of frame k+1),
     # next to the single-frame headline; a different figure, labelled as such
     pipelined, pm = None, None
@@ -839,9 +841,9 @@ def main(argv=None):
             out["config"]["other_transport"] = other_transport(m_other, args.steps)
             if transport_note:
                 out["config"]["transport_note"] = transport_note
-            out["config"]["gathered_image_vs_one_gpu_frame"] = image_checks.get(m["transport"])       # (measured above, before the choice)
+            out["config"]["gathered_image_vs_one_gpu_frame"] = m.get("image_check")       # (measured before the choice, measure_transports())
             if m_other is not None:
-                out["config"]["other_transport"]["gathered_image_vs_one_gpu_frame"] = image_checks.get(m_other["transport"])
+                out["config"]["other_transport"]["gathered_image_vs_one_gpu_frame"] = m_other.get("image_check")
         if world > 1:
             # what bounds a single frame on N GPUs, in the line itself: every peer's columns cross ONE xGMI link into rank 0
             peer_mb = BYTES_PER_PIXEL * W * H * (world - 1) / world / 1e6

@@ -130,6 +130,23 @@ def test_bench_two_ranks_on_one_gpu_store_into_the_shared_image():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_full_size_line():
+    """The same at the default size with the sphere-grid line: its image, too, is compared with one GPU's frame."""
+    env = dict(os.environ, TCRT_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "3",
+                          "--backend", "gloo", "--no-pipelined"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    whole = {"pixels_compared": 4096 * 4096, "pixels_differing": 0, "identical": True}
+    assert j["n_gpus"] == 2 and j["config"]["gathered_image_vs_one_gpu_frame"] == whole
+    g = j["sphere_grid"]
+    assert g["transport"] == "direct" and g["gathered_image_vs_one_gpu_frame"] == whole and g["value"] > 100.0
+    assert g["hbm_write_roofline"]["peak"] == 16000.0 and "cpu_baseline" not in g
+
+
+@pytest.mark.gpu
 def test_bench_prefers_the_transport_whose_image_is_right():
     """Correctness before speed: with one pixel of the direct transport's image spoiled (TCRT_BENCH_CORRUPT, a testing aid) the
     headline is the strip-buffer transport whatever the times were, and the line says why."""
