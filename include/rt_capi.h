@@ -160,8 +160,9 @@ int rt_render_multi(const rt_scene_desc *desc, const rt_camera_desc *cam, int W,
  *                   Where every GPU may address device 0's memory (peer access over xGMI) the same call also measures
  *                   the DIRECT transport -- every GPU's kernel stores its strip straight into the image on device 0,
  *                   as the reference's ranks write into the one `pixels` array; no strip buffer, no transfer, strips of
- *                   equal measured kernel time -- renders two frames of each transport on its own cut and keeps the
- *                   faster (rt_multi_info.transport, .trial_frame_ms).
+ *                   equal measured kernel time -- renders two frames of each transport on its own cut, compares sampled columns of both
+ *                   images with GPU 0's own rendering, and keeps the faster of those that are right (rt_multi_info.transport,
+ *                   .trial_frame_ms, .trial_image_ok).
  * A failed frame leaves nothing queued on any GPU and no RCCL group open; after a failed RCCL call
  * the handle refuses further frames (RT_ERR_RCCL): destroy it. */
 #define RT_MULTI_MAX_GPUS 16
@@ -176,6 +177,8 @@ typedef struct rt_multi_info {                      /* of the last rt_multi_rend
     double  frame_ms;                               /* host clock: first enqueue until everything was on device 0 */
     double  measured_kernel_ms[RT_MULTI_MAX_GPUS];  /* what the cut was computed from: every GPU's equal strip ... */
     double  measured_gather_ms;                     /* ... and the equal strips' transfers on their own */
+    int32_t trial_image_ok[2];                      /* ... and whether that transport's image equalled GPU 0's own rendering on sampled columns
+                                                     * (1 / 0; -1: not tried): a faster transport with a wrong image is not chosen */
     double  trial_frame_ms[2];                      /* the automatic choice of transport: the faster of two frames of each on its own cut, [0] RCCL, [1] direct (0: not tried) */
 } rt_multi_info;
 int rt_multi_create(const rt_scene_desc *desc, int ngpu, rt_multi **out);

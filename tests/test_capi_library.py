@@ -84,7 +84,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(capi.RtCameraDesc) == 64
     assert C.sizeof(capi.RtTiming) == 40
     assert C.sizeof(capi.RtLaunchInfo) == 24 + 48      # six int32 + kernel[48]
-    assert C.sizeof(capi.RtMultiInfo) == 4 * 4 + 4 * 17 + 4 + 8 * 16 + 8 + 8 * 16 + 8 + 8 * 2      # (4 bytes of padding before the doubles)
+    assert C.sizeof(capi.RtMultiInfo) == 4 * 4 + 4 * 17 + 4 + 8 * 16 + 8 + 8 * 16 + 8 + 4 * 2 + 8 * 2      # (4 bytes of padding before the first doubles)
 
 
 def _create(desc):

@@ -487,6 +487,7 @@ def test_multi_handle_strip_buffer_transport_and_the_trial_on_one_device(oracle,
         capi.check(lib.rt_multi_get_info(m, C.byref(info)))
         assert info.transport in (1, 2) and info.balanced == 1 and info.trial_frame_ms[0] > 0.0 and info.trial_frame_ms[1] > 0.0
         assert (info.transport == 2) == (info.trial_frame_ms[1] < info.trial_frame_ms[0])
+        assert info.trial_image_ok[0] == 1 and info.trial_image_ok[1] == 1        # both images equalled GPU 0's own on the sampled columns
         assert info.bounds[0] == 0 and info.bounds[ngpu] == W
         for transport in (1, 2, 1):
             capi.check(lib.rt_multi_set_option(m, b"transport", transport))
@@ -547,6 +548,42 @@ def test_threads_share_a_handle_and_use_their_own(oracle):
         jobs = [pool.submit(strip_on_the_shared_handle, k) for k in range(8)] + [pool.submit(own_handle, k) for k in range(8)]
         wrong = [j.result() for j in jobs if j.result()]
     assert not wrong, wrong
+
+
+@pytest.mark.parametrize("spoiled", ["rccl", "direct", "both"])
+def test_multi_handle_does_not_choose_a_transport_whose_image_is_wrong(oracle, monkeypatch, spoiled):
+    """Correctness before speed in rt_multi_render's automatic choice: with one pixel of a transport's trial image spoiled
+    (TCRT_MULTI_CORRUPT, a testing aid) the OTHER transport is used whatever the times were; with both spoiled the call fails
+    loudly instead of delivering either."""
+    import ctypes as C
+    from tilecoderaytracer_amd import capi
+    lib = capi.load_library()
+    monkeypatch.setenv("TCRT_MULTI_ONE_DEVICE", "2")
+    host, orc = HostScene.named("grid9"), oracle.OracleScene.named("grid9")
+    W, H, depth = 200, 64, 3
+    m = C.c_void_p()
+    capi.check(lib.rt_multi_create(host.desc, 3, C.byref(m)))
+    try:
+        out = np.zeros((W, H, 3), dtype=np.float32)
+        info = capi.RtMultiInfo()
+        if spoiled == "both":
+            monkeypatch.setenv("TCRT_MULTI_CORRUPT", "both")
+            assert lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data) == capi.RT_ERR_HIP
+            assert b"neither transport" in lib.rt_last_error() and not out.any()
+            monkeypatch.delenv("TCRT_MULTI_CORRUPT")                   # the handle is usable afterwards: it measures again
+            capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+            assert_same(out, orc.render(W, H, depth), "the frame after a failed choice")
+            capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+            assert info.trial_image_ok[0] == 1 and info.trial_image_ok[1] == 1
+            return
+        monkeypatch.setenv("TCRT_MULTI_CORRUPT", spoiled)
+        capi.check(lib.rt_multi_render(m, host.camera, W, H, depth, 0, out.ctypes.data))
+        assert_same(out, orc.render(W, H, depth), "the frame after the choice")
+        capi.check(lib.rt_multi_get_info(m, C.byref(info)))
+        assert info.transport == (2 if spoiled == "rccl" else 1)
+        assert (info.trial_image_ok[0], info.trial_image_ok[1]) == ((0, 1) if spoiled == "rccl" else (1, 0))
+    finally:
+        capi.check(lib.rt_multi_destroy(m))
 
 
 def test_render_multi_the_references_simulator_configuration(oracle, monkeypatch):

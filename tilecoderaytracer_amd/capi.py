@@ -78,6 +78,7 @@ class RtMultiInfo(C.Structure):
         ("frame_ms", C.c_double),
         ("measured_kernel_ms", C.c_double * RT_MULTI_MAX_GPUS),
         ("measured_gather_ms", C.c_double),
+        ("trial_image_ok", C.c_int32 * 2),
         ("trial_frame_ms", C.c_double * 2),
     ]
 

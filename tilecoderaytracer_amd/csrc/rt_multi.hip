@@ -356,6 +356,43 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+/* Correctness before speed, in the automatic choice of transport: sampled COLUMNS of the image on device 0 -- the first and last
+ * column of every strip of the cut in use and every 64th column -- against the same columns rendered by GPU 0 alone (`reference`:
+ * filled by the first call, compared by later ones).  *same = every sampled byte equal.  TCRT_MULTI_CORRUPT=rccl|direct|both
+ * (testing aid) spoils one pixel of that transport's image before it is looked at. */
+int sample_columns_check(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_depth, const std::vector<int> &columns,
+                         std::vector<float> &reference, const char *transport, bool *same) {
+    const size_t column_floats = (size_t)H * 3;
+    HIP_OR_FAIL(hipSetDevice(m->dev[0]));
+    const char *spoil = std::getenv("TCRT_MULTI_CORRUPT");
+    if (spoil && (std::strcmp(spoil, transport) == 0 || std::strcmp(spoil, "both") == 0) && !columns.empty()) {
+        const float bad = -12345.0f;
+        HIP_OR_FAIL(hipMemcpy(static_cast<float *>(m->d_full) + (size_t)columns[0] * column_floats, &bad, sizeof bad, hipMemcpyHostToDevice));
+    }
+    if (reference.empty()) {                              /* GPU 0 renders the sampled columns by itself, one at a time */
+        void *d_column = nullptr;
+        HIP_OR_FAIL(hipMalloc(&d_column, column_floats * sizeof(float)));
+        reference.resize(columns.size() * column_floats);
+        int rc = RT_OK;
+        for (size_t i = 0; i < columns.size() && rc == RT_OK; ++i) {
+            rc = rt_render_device(m->scenes[0], cam, W, H, columns[i], columns[i] + 1, max_depth, d_column, m->compute[0]);
+            if (rc == RT_OK && hipStreamSynchronize(m->compute[0]) != hipSuccess) rc = multi_fail(RT_ERR_HIP, "hipStreamSynchronize failed");
+            if (rc == RT_OK && hipMemcpy(reference.data() + i * column_floats, d_column, column_floats * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+                rc = multi_fail(RT_ERR_HIP, "hipMemcpy of a reference column failed");
+        }
+        (void)hipFree(d_column);
+        if (rc != RT_OK) { reference.clear(); return rc; }
+    }
+    std::vector<float> got(column_floats);
+    *same = true;
+    for (size_t i = 0; i < columns.size(); ++i) {
+        HIP_OR_FAIL(hipMemcpy(got.data(), static_cast<float *>(m->d_full) + (size_t)columns[i] * column_floats, column_floats * sizeof(float),
+                              hipMemcpyDeviceToHost));
+        if (std::memcmp(got.data(), reference.data() + i * column_floats, column_floats * sizeof(float)) != 0) { *same = false; break; }
+    }
+    return RT_OK;
+}
+
 /* The measured-cost partition for frames of this shape: one frame on equal strips to warm everything up (code objects, the
  * links' first use), then the kernels alone (every GPU's time for its equal strip) and the transfers alone (the time the
  * strips need to reach device 0, all peers at once, each over its own link); rt_suggest_chunks and rt_balance_strips turn that
@@ -408,6 +445,7 @@ int multi_balance(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_
     m->direct = false;
     m->info.transport = RT_MULTI_TRANSPORT_RCCL;
     m->info.trial_frame_ms[0] = m->info.trial_frame_ms[1] = 0.0;
+    m->info.trial_image_ok[0] = m->info.trial_image_ok[1] = -1;
     if (try_direct) {
         std::vector<double> direct_ms((size_t)ngpu, 0.0);
         std::vector<int> direct_cut = equal;
@@ -430,21 +468,37 @@ int multi_balance(rt_multi *m, const rt_camera_desc *cam, int W, int H, int max_
             rc = multi_reserve(m, W, H, chunks);
             if (rc) return rc;
             double best[2] = {1e300, 1e300};
+            bool right[2] = {true, true};                    /* the transport's image equals GPU 0's own rendering on the sampled columns */
+            std::vector<int> columns;
+            for (int x = 0; x < W; x += 64) columns.push_back(x);
+            for (int g = 0; g < ngpu; ++g)
+                for (const std::vector<int> *b : {&cut, &direct_cut})
+                    if ((*b)[(size_t)g + 1] > (*b)[(size_t)g]) { columns.push_back((*b)[(size_t)g]); columns.push_back((*b)[(size_t)g + 1] - 1); }
+            std::sort(columns.begin(), columns.end());
+            columns.erase(std::unique(columns.begin(), columns.end()), columns.end());
+            std::vector<float> reference;
             for (int round = 0; round < 2; ++round) {        /* the faster of two frames each: a single frame's host time is noisy */
                 m->bounds = cut;
                 double t0 = now_ms();
                 rc = multi_frame(m, cam, W, H, max_depth, chunks, true, true);
                 if (rc) return rc;
                 best[0] = std::min(best[0], now_ms() - t0);
+                if (round == 1) { rc = sample_columns_check(m, cam, W, H, max_depth, columns, reference, "rccl", &right[0]); if (rc) return rc; }
                 m->bounds = direct_cut;
                 t0 = now_ms();
                 rc = multi_frame(m, cam, W, H, max_depth, 1, true, false, true);
                 if (rc) return rc;
                 best[1] = std::min(best[1], now_ms() - t0);
+                if (round == 1) { rc = sample_columns_check(m, cam, W, H, max_depth, columns, reference, "direct", &right[1]); if (rc) return rc; }
             }
             m->info.trial_frame_ms[0] = best[0];
             m->info.trial_frame_ms[1] = best[1];
-            use_direct = best[1] < best[0];
+            m->info.trial_image_ok[0] = right[0] ? 1 : 0;
+            m->info.trial_image_ok[1] = right[1] ? 1 : 0;
+            if (!right[0] && !right[1])
+                return multi_fail(RT_ERR_HIP, "neither transport delivered the image GPU 0 renders by itself (sampled columns differ)");
+            /* correctness before speed: the faster transport only if its image is right */
+            use_direct = right[1] && (best[1] < best[0] || !right[0]);
         }
         if (use_direct) {
             cut = direct_cut;
